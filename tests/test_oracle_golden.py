@@ -1,0 +1,53 @@
+"""Pin the CPU oracle (oracle/torch_oracle.py) against outputs of the reference itself.
+
+Fixtures under tests/golden/*.npz were produced by tests/golden/make_golden.py running the
+reference's WaveGlow.infer / forward / WaveGlowLoss in the build container.  Same torch
+build, same ops, same order -> the restatement must agree bit for bit on CPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _cases import Case
+from oracle import torch_oracle as O
+
+CASES = ["tiny", "c64", "c256", "c512"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_weight_generator_is_stable(name):
+  c = Case(name)
+  assert c.weights_crc() == int(c.npz["weights_crc32"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_infer_matches_reference_bitwise(name):
+  c = Case(name)
+  torch.set_num_threads(8)
+  with torch.no_grad():
+    audio = O.infer_ref(c.sd, c.mel, c.z_init, c.z_early, c.sigma, c.oracle_cfg())
+  assert audio.shape == c.audio.shape
+  assert torch.equal(audio, c.audio), float((audio - c.audio).abs().max())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_and_loss_match_reference_bitwise(name):
+  c = Case(name)
+  wav = torch.from_numpy(c.npz["fwd_audio_in"])
+  with torch.no_grad():
+    z, log_s, log_det = O.forward_ref(c.sd, c.mel, wav, c.oracle_cfg())
+    loss = O.loss_ref(z, log_s, log_det, sigma=1.0)
+  assert torch.equal(z, torch.from_numpy(c.npz["fwd_z"]))
+  for k, ls in enumerate(log_s):
+    assert torch.equal(ls, torch.from_numpy(c.npz[f"fwd_log_s_{k}"])), k
+  np.testing.assert_array_equal(np.array([float(x) for x in log_det], dtype=np.float32), c.npz["fwd_log_det"])
+  assert np.float32(float(loss)) == c.npz["fwd_loss"]
+
+
+@pytest.mark.parametrize("name", ["tiny", "c64"])
+def test_weightnorm_checkpoint_form(name):
+  """The 686-key checkpoint form folds (g*v/||v||) to the dense weights within fp32 rounding."""
+  c = Case(name)
+  ref = torch.from_numpy(c.npz["audio_from_weightnorm_ckpt"])
+  # reference-through-its-own-fold differs from the dense-weight run only by fold rounding
+  assert float((ref - c.audio).abs().max()) < 5e-4
