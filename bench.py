@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WaveGlow-256 inference throughput (audio samples/s at 22.05 kHz) on MI355X.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One step = one ``WaveGlow.infer`` pass (model.py:223-274 of the reference: upsample, 12 flows x 8 WN layers,
+noise draws included) over one batch of BASELINE.json configs[1]: LJS-v3-shaped 256-channel model (synthetic
+weights, identical architecture/format), batch 16 of random 80x864 mels, fp16 I/O, sigma 0.6.  Inputs are
+resident in HBM before the timed region.  Multi-GPU = independent utterance shards per rank (no collective on
+the data path); per-GPU work is fixed => weak scaling.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP16_DENSE_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def wn_layer_macs_per_group_step(hp) -> float:
+  """Algorithmic MACs of ALL WN-layer launches per group-timestep (SURVEY.md 8(d) terms that the wn_layer
+  kernel covers: cond slice + dilated in_layer + res_skip of every layer, plus WN.end)."""
+  C_, NS = hp.n_channels, hp.n_mel_channels * hp.n_group
+  per_flow = NS * 2 * C_ * hp.n_layers + hp.n_layers * (C_ * 2 * C_ * hp.kernel_size) + \
+      (hp.n_layers - 1) * (C_ * 2 * C_) + C_ * C_
+  total, rem = 0.0, hp.n_group
+  for k in range(hp.n_flows):
+    if k % hp.n_early_every == 0 and k > 0:
+      rem -= hp.n_early_size
+    total += per_flow + C_ * rem   # end: C x 2h_k
+  return total
+
+
+def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
+  """The CPU oracle (port of the reference's fp32 infer, verified bit-equal to the reference in the build
+  container) timed on this host's cores on a bounded sample: configs[0] shape, mel [1,80,500]."""
+  from oracle import torch_oracle as O
+  from waveglow_amd import synthetic
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  from _cases import oracle_cfg_from_hp
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)   # reference CLI: set_torch_thread_to_max (src/waveglow/utils.py:27-29)
+  cfg = oracle_cfg_from_hp(hp)
+  T = 500
+  mel = synthetic.make_mel(1, T)
+  z_init, z_early = synthetic.make_noise(hp, 1, 32 * T)
+  with torch.no_grad():
+    O.infer_ref(sd, mel[:, :, :20], z_init[:, :, :640], {k: v[:, :, :640] for k, v in z_early.items()}, 0.6, cfg)
+    best = None
+    t_all = time.perf_counter()
+    for _ in range(3):
+      t0 = time.perf_counter()
+      O.infer_ref(sd, mel, z_init, z_early, 0.6, cfg)
+      dt = time.perf_counter() - t0
+      best = dt if best is None else min(best, dt)
+      if time.perf_counter() - t_all > seconds_hint:
+        break
+  return {"value": round(256 * T / best, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+          "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}] (configs[0] shape), best of <=3, {best:.2f} s"}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--batch", type=int, default=16)
+  ap.add_argument("--frames", type=int, default=864)
+  ap.add_argument("--channels", type=int, default=256)
+  ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    if args.gpus != 1 or world != 1:
+      raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=dev)
+
+  from waveglow_amd import synthetic
+  from waveglow_amd.hparams import HParams
+  from waveglow_amd.model import WaveGlow
+
+  hp = HParams(n_channels=args.channels)
+  sd = synthetic.make_state_dict(hp, seed=0)
+  model = WaveGlow.remove_weightnorm(WaveGlow(hp))
+  model.load_state_dict(sd)
+  dtype = torch.float16 if args.dtype == "fp16" else torch.float32
+  model = model.to(dev).eval()
+  B, T = args.batch, args.frames
+  mel = synthetic.make_mel(B, T, seed=1234 + rank).to(dev, dtype)
+  sigma = 0.6
+  torch.manual_seed(4321 + rank)
+
+  with torch.no_grad():
+    for _ in range(args.warmup):
+      audio = model.infer(mel, sigma=sigma)
+    eng = model._engine
+    eng.lib.wg_profile_enable(eng.handle, 1)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+      dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      audio = model.infer(mel, sigma=sigma)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+      dist.barrier()
+    elapsed = time.perf_counter() - t0
+  assert torch.isfinite(audio).all()
+
+  ms = (C.c_double * 4)()
+  cnt = (C.c_int64 * 4)()
+  eng.lib.wg_profile_read(eng.handle, ms, cnt, 4)
+  eng.lib.wg_profile_enable(eng.handle, 0)
+
+  if dist is not None:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  if rank == 0:
+    samples_per_step = B * T * 256 * world
+    value = samples_per_step * args.steps / elapsed
+    n_wn = int(cnt[2])
+    avg_wn_ms = ms[2] / max(1, n_wn)
+    launches_per_step = hp.n_flows * hp.n_layers
+    flops_per_launch = 2.0 * wn_layer_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
+    achieved = flops_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
+    out = {
+      "metric": "audio samples/sec/GPU (22.05 kHz) WaveGlow-256 infer; real-time factor",
+      "value": round(value, 1),
+      "unit": "samples/s",
+      "n_gpus": world,
+      "steps": args.steps,
+      "warmup": args.warmup,
+      "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+      "higher_is_better": True,
+      "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "f16 MFMA operands, f32 accumulate/flow state, %s I/O" % args.dtype,
+      "data": "synthetic (random 80xT log-mels, synthetic weights of the LJS-v3 256ch architecture)",
+      "config": {"workload": f"configs[1]: {args.channels}ch WaveGlow.infer, batch={B}/GPU mels 80x{T}, sigma=0.6",
+                 "per_gpu_samples_per_step": B * T * 256, "parallelism": f"utterance-sharded x{world}, no collective"},
+      "real_time_factor": round(value / 22050.0, 1),
+      "samples_per_s_per_gpu": round(value / world, 1),
+      "roofline": {"bound": "mfma", "kernel": "wn_layer_kernel", "achieved": round(achieved, 2),
+                   "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4),
+                   "traffic": None, "avg_launch_ms": round(avg_wn_ms, 4), "launches_timed": n_wn,
+                   "algorithmic_flops_per_launch": flops_per_launch,
+                   "kernel_ms_per_step": {"upsample": round(ms[0] / args.steps, 3), "flow_start": round(ms[1] / args.steps, 3),
+                                          "wn_layer": round(ms[2] / args.steps, 3), "memset": round(ms[3] / args.steps, 3)}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(hp, sd)
+    print(json.dumps(out), flush=True)
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,123 @@
+/*
+ * waveglow_amd.h -- C ABI of the MI355X-native WaveGlow hot path (libwaveglow_amd.so).
+ *
+ * The reference (stefantaubert/waveglow) is pure Python and has no FFI of its own; the
+ * interface this library replaces is the set of Python methods on its model object
+ * (paths relative to /root/reference/):
+ *
+ *   wg_create / wg_set_tensor / wg_finalize  <-  WaveGlow.__init__ (src/waveglow/model.py:141-176),
+ *       load_model -> load_state_dict (src/waveglow/train.py:48-55) and
+ *       WaveGlow.remove_weightnorm (model.py:276-297): tensors are handed over by their
+ *       state_dict names in weight-norm-removed form.
+ *   wg_infer    <-  WaveGlow.infer(spect, sigma)          (model.py:223-274)
+ *   wg_forward  <-  WaveGlow.forward((spect, audio))       (model.py:178-221)
+ *
+ * Conventions: plain pointers and sizes only.  `mel`, noise, outputs and `workspace` are DEVICE
+ * pointers owned by the caller; weights given to wg_set_tensor are HOST fp32 pointers and are
+ * copied.  Every call returns 0 on success or a negative wg_status; wg_last_error() gives the
+ * message of the last failure on the calling thread.  wg_infer / wg_forward only enqueue work on
+ * `stream` (a hipStream_t passed as void*); they never synchronise, allocate or free.
+ * One handle per device; a handle may be used from one stream at a time.
+ */
+#ifndef WAVEGLOW_AMD_H
+#define WAVEGLOW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wg_handle wg_handle;
+
+typedef enum wg_status {
+  WG_OK = 0,
+  WG_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+  WG_ERR_STATE = -2,        /* call order (e.g. infer before finalize, missing tensor) */
+  WG_ERR_HIP = -3,          /* HIP runtime error (message has the hipError string) */
+  WG_ERR_WORKSPACE = -4     /* workspace too small */
+} wg_status;
+
+typedef enum wg_dtype { WG_F32 = 0, WG_F16 = 1 } wg_dtype;
+
+/* Model-shaping fields of ModelHParams (src/waveglow/hparams.py:19-31) plus the fixed
+ * upsample geometry of model.py:145-150. */
+typedef struct wg_config {
+  int32_t n_mel_channels;   /* 80 */
+  int32_t n_flows;          /* 12 */
+  int32_t n_group;          /* 8 (only 8 is supported) */
+  int32_t n_early_every;    /* 4 */
+  int32_t n_early_size;     /* 2 */
+  int32_t n_layers;         /* 8 (dilation 2^i, i < n_layers; <= 8) */
+  int32_t n_channels;       /* 64, 128, 256 or 512 */
+  int32_t kernel_size;      /* 3 (only 3 is supported) */
+  int32_t upsample_kernel;  /* 1024 */
+  int32_t upsample_stride;  /* 256 */
+} wg_config;
+
+const char* wg_version(void);
+const char* wg_last_error(void);
+
+/* WaveGlow.__init__ (model.py:141-176): validates the configuration, selects device `device_id`. */
+int wg_create(const wg_config* cfg, int device_id, wg_handle** out);
+int wg_destroy(wg_handle* h);
+
+/* One tensor of the weight-norm-removed state_dict (model.py:276-297), fp32, host memory, C order.
+ * Names and shapes are the reference's: "upsample.weight" [M,M,K], "upsample.bias" [M],
+ * "convinv.k.conv.weight" [c_k,c_k,1], "WN.k.start.{weight [C,h_k,1],bias [C]}",
+ * "WN.k.cond_layer.{weight [2C*n_layers, M*8, 1], bias}", "WN.k.in_layers.i.{weight [2C,C,3], bias}",
+ * "WN.k.res_skip_layers.i.{weight [2C or C, C, 1], bias}", "WN.k.end.{weight [2h_k,C,1], bias}". */
+int wg_set_tensor(wg_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+
+/* Number of tensors wg_finalize expects, and the i-th expected name (for host-side checks). */
+int wg_num_expected_tensors(const wg_handle* h);
+const char* wg_expected_tensor_name(const wg_handle* h, int32_t i);
+
+/* Packs all tensors into the kernels' MFMA fragment layouts (fp16 operands, fp32 biases), inverts the
+ * 1x1 matrices in fp64 (model.py:51-60: W.float().inverse()), and uploads them.  May be called again
+ * after further wg_set_tensor calls (derived state is rebuilt; no stale W^-1, unlike model.py:52-58). */
+int wg_finalize(wg_handle* h);
+
+/* Bytes of device workspace wg_infer / wg_forward need for batch B and n_frames mel frames
+ * (forward: audio_len samples per utterance, a multiple of n_group). 0 on invalid arguments. */
+size_t wg_infer_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames);
+size_t wg_forward_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len);
+
+/* WaveGlow.infer (model.py:223-274) with the noise injected (the caller draws it, keeping the
+ * reference's RNG order: z_init [B, n_rem, L] first, then one [B, n_early_size, L] per early-output
+ * flow in DESCENDING flow index; L = n_frames*upsample_stride/n_group).
+ *   mel      [B, n_mel, n_frames]           io_dtype
+ *   z_init   [B, n_rem, L]                  io_dtype
+ *   z_early  n_z_early device pointers, each [B, n_early_size, L], io_dtype
+ *   audio    [B, n_frames*upsample_stride]  io_dtype (output)
+ * Arithmetic: fp16 MFMA operands, fp32 accumulation, fp32 flow state. */
+int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* const* z_early,
+             int32_t n_z_early, float sigma, void* audio, int32_t B, int32_t n_frames,
+             int32_t io_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* WaveGlow.forward (model.py:178-221), inference of the normalising direction (no autograd).
+ *   mel      [B, n_mel, n_frames]     io_dtype
+ *   audio    [B, audio_len]           io_dtype; audio_len % n_group == 0 and
+ *                                     audio_len <= (n_frames-1)*stride + kernel  (model.py:187)
+ *   z        [B, n_group, L]          fp32 out, L = audio_len / n_group
+ *   log_s    n_flows device pointers, log_s[k] is [B, h_k, L] fp32 out
+ *   log_det_W  HOST pointer to n_flows floats: B*L*logdet(W_k) (model.py:63), written before return */
+int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float* const* log_s,
+               float* log_det_W, int32_t B, int32_t n_frames, int32_t audio_len, int32_t io_dtype,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Algorithmic MACs per group-timestep (8 samples) of one infer pass, as SURVEY.md section 8(d) counts
+ * them (for roofline reporting). */
+double wg_macs_per_group_step(const wg_handle* h);
+
+/* Per-kernel device timing: when enabled, wg_infer brackets its kernels with hipEvents on `stream`;
+ * wg_profile_read synchronises those events and returns accumulated milliseconds per kernel class.
+ * classes: 0 = upsample, 1 = flow/start, 2 = wn_layer, 3 = other. */
+int wg_profile_enable(wg_handle* h, int32_t on);
+int wg_profile_read(wg_handle* h, double* ms_per_class, int64_t* launches_per_class, int32_t n_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEGLOW_AMD_H */

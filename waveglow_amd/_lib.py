@@ -1,0 +1,72 @@
+"""ctypes binding of libwaveglow_amd.so (C ABI: include/waveglow_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``waveglow_amd.build.build_library()``.
+There is no fallback: if it is missing or fails to load, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwaveglow_amd.so")
+
+WG_F32, WG_F16 = 0, 1
+
+
+class WgConfig(C.Structure):
+  _fields_ = [(n, C.c_int32) for n in (
+    "n_mel_channels", "n_flows", "n_group", "n_early_every", "n_early_size", "n_layers",
+    "n_channels", "kernel_size", "upsample_kernel", "upsample_stride")]
+
+
+class WgError(RuntimeError):
+  pass
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); every symbol declared in include/waveglow_amd.h
+SIGNATURES = {
+  "wg_version": (C.c_char_p, []),
+  "wg_last_error": (C.c_char_p, []),
+  "wg_create": (C.c_int, [C.POINTER(WgConfig), C.c_int, C.POINTER(C.c_void_p)]),
+  "wg_destroy": (C.c_int, [C.c_void_p]),
+  "wg_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+  "wg_num_expected_tensors": (C.c_int, [C.c_void_p]),
+  "wg_expected_tensor_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+  "wg_finalize": (C.c_int, [C.c_void_p]),
+  "wg_infer_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+  "wg_forward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+  "wg_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_float,
+                         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+  "wg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                           C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                           C.c_void_p, C.c_size_t, C.c_void_p]),
+  "wg_macs_per_group_step": (C.c_double, [C.c_void_p]),
+  "wg_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+  "wg_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+}
+
+
+def load() -> C.CDLL:
+  """Load the HIP library or raise -- never falls back to another implementation."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.isfile(LIB_PATH):
+    raise WgError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                  "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+  lib = C.CDLL(LIB_PATH)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)
+    fn.restype = res
+    fn.argtypes = args
+  _lib = lib
+  return lib
+
+
+def check(rc: int) -> None:
+  if rc != 0:
+    raise WgError(f"libwaveglow_amd error {rc}: {load().wg_last_error().decode()}")

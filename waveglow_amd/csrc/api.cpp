@@ -1,0 +1,741 @@
+// Host side of libwaveglow_amd: C ABI (include/waveglow_amd.h), weight packing, launch sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/waveglow_amd.h"
+#include "wg_common.h"
+
+using namespace wg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) return fail(WG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// fp64 Gauss-Jordan inverse with partial pivoting; also log|det| and sign.
+bool invert(const std::vector<double>& A, int n, std::vector<double>& inv, double& logabsdet, int& sign) {
+  std::vector<double> M(A);
+  inv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+  logabsdet = 0.0;
+  sign = 1;
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(M[(size_t)r * n + c]) > std::fabs(M[(size_t)piv * n + c])) piv = r;
+    if (M[(size_t)piv * n + c] == 0.0) return false;
+    if (piv != c) {
+      for (int k = 0; k < n; ++k) {
+        std::swap(M[(size_t)piv * n + k], M[(size_t)c * n + k]);
+        std::swap(inv[(size_t)piv * n + k], inv[(size_t)c * n + k]);
+      }
+      sign = -sign;
+    }
+    const double d = M[(size_t)c * n + c];
+    logabsdet += std::log(std::fabs(d));
+    if (d < 0) sign = -sign;
+    for (int k = 0; k < n; ++k) {
+      M[(size_t)c * n + k] /= d;
+      inv[(size_t)c * n + k] /= d;
+    }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = M[(size_t)r * n + c];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; ++k) {
+        M[(size_t)r * n + k] -= f * M[(size_t)c * n + k];
+        inv[(size_t)r * n + k] -= f * inv[(size_t)c * n + k];
+      }
+    }
+  }
+  return true;
+}
+
+struct LayerOffsets {
+  size_t wA1, bias1, wA2, bias2, wEs;
+};
+struct FlowOffsets {
+  std::vector<LayerOffsets> layers;
+  size_t wstart, bstart, out_init, winv, wfwd;
+  int c, h;
+  double logdet;   // log|det W_k|, NaN when det < 0 (torch.logdet semantics, model.py:63)
+};
+
+}  // namespace
+
+struct wg_handle {
+  wg_config cfg;
+  int device;
+  int NS;                 // n_mel * n_group
+  std::vector<int> c_k;   // remaining channels per flow (model.py:160-176)
+  std::vector<std::string> expected;
+  std::map<std::string, HostTensor> tensors;
+  bool finalized = false;
+  char* d_blob = nullptr;
+  size_t blob_bytes = 0;
+  size_t off_upw = 0, off_upb = 0;
+  std::vector<FlowOffsets> flows;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_class;
+  size_t ev_used = 0;
+  double prof_ms[4] = {0, 0, 0, 0};
+  int64_t prof_n[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+std::vector<int> flow_channels(const wg_config& c) {
+  std::vector<int> out;
+  int rem = c.n_group;
+  for (int k = 0; k < c.n_flows; ++k) {
+    if (k % c.n_early_every == 0 && k > 0) rem -= c.n_early_size;
+    out.push_back(rem);
+  }
+  return out;
+}
+
+bool is_early(const wg_config& c, int k) { return k % c.n_early_every == 0 && k > 0; }
+
+RowGeom make_geom(const wg_config& c, int B, int L) {
+  RowGeom g;
+  g.B = B;
+  g.L = L;
+  g.Ltile = (L + 127) / 128 * 128;
+  g.G = 128;
+  while (g.G < (1 << (c.n_layers - 1))) g.G *= 2;
+  g.Lp = g.G + g.Ltile + g.G;
+  g.R = B * g.Lp;
+  return g;
+}
+
+struct Workspace {
+  _Float16 *S, *X0, *X1;
+  float *Z, *OUT;
+  size_t bytes;
+  size_t x_bytes, s_bytes;
+};
+
+Workspace carve(const wg_handle* h, const RowGeom& g, char* base) {
+  Workspace w;
+  size_t off = 0;
+  const int C = h->cfg.n_channels;
+  w.s_bytes = align_up((size_t)h->NS * g.R * 2);
+  w.x_bytes = align_up((size_t)C * g.R * 2);
+  w.S = (_Float16*)(base + off); off += w.s_bytes;
+  w.X0 = (_Float16*)(base + off); off += w.x_bytes;
+  w.X1 = (_Float16*)(base + off); off += w.x_bytes;
+  w.Z = (float*)(base + off); off += align_up((size_t)g.B * g.L * 8 * 4);
+  w.OUT = (float*)(base + off); off += align_up((size_t)g.B * g.L * 8 * 4);
+  w.bytes = off;
+  return w;
+}
+
+const HostTensor* find(const wg_handle* h, const std::string& name) {
+  auto it = h->tensors.find(name);
+  return it == h->tensors.end() ? nullptr : &it->second;
+}
+
+struct Prof {
+  wg_handle* h;
+  hipStream_t s;
+  int cls;
+  Prof(wg_handle* h_, hipStream_t s_, int cls_) : h(h_), s(s_), cls(cls_) {
+    if (h->prof) rec();
+  }
+  ~Prof() {
+    if (h->prof) rec();
+  }
+  void rec() {
+    if (h->ev_used == h->ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      h->ev.push_back(e);
+      h->ev_class.push_back(0);
+    }
+    h->ev_class[h->ev_used] = cls;
+    hipEventRecord(h->ev[h->ev_used++], s);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* wg_version(void) { return "waveglow_amd 0.1 (gfx950)"; }
+const char* wg_last_error(void) { return g_err.c_str(); }
+
+int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
+  if (!cfg || !out) return fail(WG_ERR_INVALID, "null argument");
+  const wg_config& c = *cfg;
+  if (c.n_group != 8) return fail(WG_ERR_INVALID, "n_group=%d unsupported (only 8)", c.n_group);
+  if (c.kernel_size != 3) return fail(WG_ERR_INVALID, "kernel_size=%d unsupported (only 3)", c.kernel_size);
+  if (c.n_channels != 64 && c.n_channels != 128 && c.n_channels != 256 && c.n_channels != 512)
+    return fail(WG_ERR_INVALID, "n_channels=%d unsupported (64, 128, 256, 512)", c.n_channels);
+  if (c.n_layers < 1 || c.n_layers > 8) return fail(WG_ERR_INVALID, "n_layers=%d unsupported (1..8)", c.n_layers);
+  if (c.upsample_kernel != 1024 || c.upsample_stride != 256)
+    return fail(WG_ERR_INVALID, "upsample geometry %d/%d unsupported (1024/256)", c.upsample_kernel, c.upsample_stride);
+  if (c.n_mel_channels < 1 || c.n_mel_channels > 80 || (c.n_mel_channels * c.n_group) % 64 != 0)
+    return fail(WG_ERR_INVALID, "n_mel_channels=%d unsupported (multiple of 8, <= 80)", c.n_mel_channels);
+  if (c.n_flows < 1 || c.n_early_every < 1 || c.n_early_size < 0 || c.n_early_size % 2 != 0)
+    return fail(WG_ERR_INVALID, "bad flow configuration");
+  std::vector<int> ck = flow_channels(c);
+  if (ck.back() < 2 || ck.back() % 2 != 0) return fail(WG_ERR_INVALID, "flow configuration leaves %d channels", ck.back());
+  wg_handle* h = new wg_handle();
+  h->cfg = c;
+  h->device = device_id;
+  h->NS = c.n_mel_channels * c.n_group;
+  h->c_k = ck;
+  h->expected.push_back("upsample.weight");
+  h->expected.push_back("upsample.bias");
+  for (int k = 0; k < c.n_flows; ++k) {
+    const std::string ks = std::to_string(k);
+    h->expected.push_back("convinv." + ks + ".conv.weight");
+    const std::string p = "WN." + ks + ".";
+    for (const char* n : {"start", "cond_layer", "end"}) {
+      h->expected.push_back(p + n + ".weight");
+      h->expected.push_back(p + n + ".bias");
+    }
+    for (int i = 0; i < c.n_layers; ++i) {
+      const std::string is = std::to_string(i);
+      h->expected.push_back(p + "in_layers." + is + ".weight");
+      h->expected.push_back(p + "in_layers." + is + ".bias");
+      h->expected.push_back(p + "res_skip_layers." + is + ".weight");
+      h->expected.push_back(p + "res_skip_layers." + is + ".bias");
+    }
+  }
+  *out = h;
+  return WG_OK;
+}
+
+int wg_destroy(wg_handle* h) {
+  if (!h) return WG_OK;
+  if (h->d_blob) hipFree(h->d_blob);
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  delete h;
+  return WG_OK;
+}
+
+int wg_num_expected_tensors(const wg_handle* h) { return h ? (int)h->expected.size() : 0; }
+const char* wg_expected_tensor_name(const wg_handle* h, int32_t i) {
+  if (!h || i < 0 || i >= (int)h->expected.size()) return nullptr;
+  return h->expected[i].c_str();
+}
+
+int wg_set_tensor(wg_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!h || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(WG_ERR_INVALID, "bad argument to wg_set_tensor");
+  bool known = false;
+  for (const auto& e : h->expected) known |= (e == name);
+  if (!known) return fail(WG_ERR_INVALID, "unexpected tensor name '%s'", name);
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] <= 0) return fail(WG_ERR_INVALID, "bad shape for '%s'", name);
+    t.shape.push_back(shape[i]);
+    n *= (size_t)shape[i];
+  }
+  t.data.assign(data, data + n);
+  h->tensors[name] = std::move(t);
+  h->finalized = false;
+  return WG_OK;
+}
+
+static int check_shape(const wg_handle* h, const std::string& name, std::initializer_list<int64_t> want,
+                       const HostTensor** out) {
+  const HostTensor* t = find(h, name);
+  if (!t) return fail(WG_ERR_STATE, "missing tensor '%s'", name.c_str());
+  std::vector<int64_t> w(want);
+  if (t->shape != w) {
+    std::string got, exp;
+    for (auto v : t->shape) got += std::to_string(v) + ",";
+    for (auto v : w) exp += std::to_string(v) + ",";
+    return fail(WG_ERR_INVALID, "tensor '%s' has shape [%s] expected [%s]", name.c_str(), got.c_str(), exp.c_str());
+  }
+  *out = t;
+  return WG_OK;
+}
+
+int wg_finalize(wg_handle* h) {
+  if (!h) return fail(WG_ERR_INVALID, "null handle");
+  const wg_config& c = h->cfg;
+  const int C = c.n_channels, M = c.n_mel_channels, NS = h->NS, NL = c.n_layers;
+  const int NW = C / 32, CC = C / 64, K2 = C / 16, nK = 3 * CC + NS / 64;
+  std::vector<char> blob;
+  auto reserve = [&](size_t bytes) {
+    size_t off = align_up(blob.size());
+    blob.resize(off + bytes, 0);
+    return off;
+  };
+  int rc;
+  // ---- upsample: w_p[t'][j][i][o*8+g] = W[i][o][8t'+g+256j]   (ConvTranspose1d weight is [in][out][k])
+  const HostTensor *upw, *upb;
+  if ((rc = check_shape(h, "upsample.weight", {M, M, c.upsample_kernel}, &upw))) return rc;
+  if ((rc = check_shape(h, "upsample.bias", {M}, &upb))) return rc;
+  {
+    const int NCH = M * 8;
+    h->off_upw = reserve((size_t)32 * 4 * M * NCH * 4);
+    float* wp = (float*)(blob.data() + h->off_upw);
+    for (int tp = 0; tp < 32; ++tp)
+      for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < M; ++i)
+          for (int o = 0; o < M; ++o)
+            for (int g = 0; g < 8; ++g)
+              wp[(((size_t)tp * 4 + j) * M + i) * NCH + o * 8 + g] =
+                  upw->data[((size_t)i * M + o) * c.upsample_kernel + 8 * tp + g + 256 * j];
+    h->off_upb = reserve((size_t)M * 4);
+    memcpy(blob.data() + h->off_upb, upb->data.data(), (size_t)M * 4);
+  }
+  h->flows.assign(c.n_flows, FlowOffsets());
+  for (int k = 0; k < c.n_flows; ++k) {
+    FlowOffsets& fo = h->flows[k];
+    const int ck = h->c_k[k], hk = ck / 2;
+    fo.c = ck;
+    fo.h = hk;
+    const std::string ks = std::to_string(k), p = "WN." + ks + ".";
+    const HostTensor *wci, *wst, *bst, *wcond, *bcond, *wend, *bend;
+    if ((rc = check_shape(h, "convinv." + ks + ".conv.weight", {ck, ck, 1}, &wci))) return rc;
+    if ((rc = check_shape(h, p + "start.weight", {C, hk, 1}, &wst))) return rc;
+    if ((rc = check_shape(h, p + "start.bias", {C}, &bst))) return rc;
+    if ((rc = check_shape(h, p + "cond_layer.weight", {2 * C * NL, NS, 1}, &wcond))) return rc;
+    if ((rc = check_shape(h, p + "cond_layer.bias", {2 * C * NL}, &bcond))) return rc;
+    if ((rc = check_shape(h, p + "end.weight", {2 * hk, C, 1}, &wend))) return rc;
+    if ((rc = check_shape(h, p + "end.bias", {2 * hk}, &bend))) return rc;
+    // 1x1 invertible conv: forward matrix, fp64 inverse, log|det|
+    {
+      std::vector<double> A((size_t)ck * ck), inv;
+      for (int i = 0; i < ck * ck; ++i) A[i] = wci->data[i];
+      double lad;
+      int sign;
+      if (!invert(A, ck, inv, lad, sign)) return fail(WG_ERR_INVALID, "convinv.%d weight is singular", k);
+      fo.logdet = sign > 0 ? lad : std::nan("");
+      fo.winv = reserve((size_t)ck * ck * 4);
+      fo.wfwd = reserve((size_t)ck * ck * 4);
+      float* wi = (float*)(blob.data() + fo.winv);
+      float* wf = (float*)(blob.data() + fo.wfwd);
+      for (int i = 0; i < ck * ck; ++i) {
+        wi[i] = (float)inv[i];
+        wf[i] = wci->data[i];
+      }
+    }
+    // start conv, position-major rows
+    fo.wstart = reserve((size_t)C * hk * 4);
+    fo.bstart = reserve((size_t)C * 4);
+    {
+      float* ws = (float*)(blob.data() + fo.wstart);
+      float* bs = (float*)(blob.data() + fo.bstart);
+      for (int P = 0; P < C; ++P) {
+        const int ch = pos_to_chan(P);
+        for (int j = 0; j < hk; ++j) ws[P * hk + j] = wst->data[(size_t)ch * hk + j];
+        bs[P] = bst->data[ch];
+      }
+    }
+    std::vector<double> out_bias(8, 0.0);
+    for (int r = 0; r < 2 * hk; ++r) out_bias[r] = bend->data[r];
+    fo.layers.assign(NL, LayerOffsets());
+    for (int i = 0; i < NL; ++i) {
+      LayerOffsets& lo = fo.layers[i];
+      const std::string is = std::to_string(i);
+      const bool has_res = i < NL - 1;
+      const int RS = has_res ? 2 * C : C;
+      const HostTensor *win, *bin, *wrs, *brs;
+      if ((rc = check_shape(h, p + "in_layers." + is + ".weight", {2 * C, C, 3}, &win))) return rc;
+      if ((rc = check_shape(h, p + "in_layers." + is + ".bias", {2 * C}, &bin))) return rc;
+      if ((rc = check_shape(h, p + "res_skip_layers." + is + ".weight", {RS, C, 1}, &wrs))) return rc;
+      if ((rc = check_shape(h, p + "res_skip_layers." + is + ".bias", {RS}, &brs))) return rc;
+      // GEMM1 A fragments [nK][NW][2][4][64][8]
+      lo.wA1 = reserve((size_t)nK * NW * 8 * 64 * 8 * 2);
+      {
+        _Float16* dst = (_Float16*)(blob.data() + lo.wA1);
+        for (int ksx = 0; ksx < nK; ++ksx)
+          for (int w = 0; w < NW; ++w)
+            for (int mt = 0; mt < 2; ++mt)
+              for (int k16 = 0; k16 < 4; ++k16)
+                for (int lane = 0; lane < 64; ++lane) {
+                  const int r = lane & 31, hh = lane >> 5;
+                  const int m = mt * C + 32 * w + r;
+                  _Float16* d = dst + (((((size_t)ksx * NW + w) * 2 + mt) * 4 + k16) * 64 + lane) * 8;
+                  for (int j = 0; j < 8; ++j) {
+                    const int kk = k16 * 16 + 8 * hh + j;
+                    float v;
+                    if (ksx < 3 * CC) {
+                      const int tap = ksx / CC, cc = ksx % CC;
+                      const int ch = pos_to_chan(cc * 64 + kk);
+                      v = win->data[((size_t)m * C + ch) * 3 + tap];
+                    } else {
+                      const int s = (ksx - 3 * CC) * 64 + kk;
+                      v = wcond->data[((size_t)(2 * C * i + m)) * NS + s];
+                    }
+                    d[j] = (_Float16)v;
+                  }
+                }
+      }
+      lo.bias1 = reserve((size_t)2 * C * 4);
+      {
+        float* b1 = (float*)(blob.data() + lo.bias1);
+        for (int m = 0; m < 2 * C; ++m) b1[m] = bin->data[m] + bcond->data[2 * C * i + m];
+      }
+      // GEMM2 (res) A fragments [NW][K2][64][8], bias2
+      lo.wA2 = reserve((size_t)NW * K2 * 64 * 8 * 2);
+      lo.bias2 = reserve((size_t)C * 4);
+      if (has_res) {
+        _Float16* dst = (_Float16*)(blob.data() + lo.wA2);
+        for (int w = 0; w < NW; ++w)
+          for (int k16 = 0; k16 < K2; ++k16)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int r = lane & 31, hh = lane >> 5;
+              const int m = 32 * w + r;
+              _Float16* d = dst + (((size_t)w * K2 + k16) * 64 + lane) * 8;
+              for (int j = 0; j < 8; ++j) {
+                const int ch = pos_to_chan(k16 * 16 + 8 * hh + j);
+                d[j] = (_Float16)wrs->data[(size_t)m * C + ch];
+              }
+            }
+        float* b2 = (float*)(blob.data() + lo.bias2);
+        for (int m = 0; m < C; ++m) b2[m] = brs->data[m];
+      }
+      // folded end x skip: Wes = W_end (2h x C) * W_skip_i (C x C), fp64; hi/lo fp16 split
+      const int skip_row0 = has_res ? C : 0;
+      std::vector<double> Wes((size_t)8 * C, 0.0);
+      for (int r = 0; r < 2 * hk; ++r) {
+        for (int m = 0; m < C; ++m) {
+          const double we = wend->data[(size_t)r * C + m];
+          const float* wrow = &wrs->data[(size_t)(skip_row0 + m) * C];
+          for (int cch = 0; cch < C; ++cch) Wes[(size_t)r * C + cch] += we * wrow[cch];
+          out_bias[r] += we * brs->data[skip_row0 + m];
+        }
+      }
+      lo.wEs = reserve((size_t)(C / 32) * 64 * 8 * 2);
+      {
+        _Float16* dst = (_Float16*)(blob.data() + lo.wEs);
+        for (int s = 0; s < C / 32; ++s)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 15, l4 = lane >> 4;
+            for (int j = 0; j < 8; ++j) {
+              const int ch = pos_to_chan(32 * s + 8 * l4 + j);
+              const float v = (float)Wes[(size_t)(row & 7) * C + ch];
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo16 = (_Float16)(v - (float)hi);
+              dst[((size_t)s * 64 + lane) * 8 + j] = row < 8 ? hi : lo16;
+            }
+          }
+      }
+    }
+    fo.out_init = reserve(8 * 4);
+    {
+      float* oi = (float*)(blob.data() + fo.out_init);
+      for (int r = 0; r < 8; ++r) oi[r] = (float)out_bias[r];
+    }
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->d_blob) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(h->d_blob));
+    h->d_blob = nullptr;
+  }
+  HIP_TRY(hipMalloc((void**)&h->d_blob, blob.size()));
+  HIP_TRY(hipMemcpy(h->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  h->blob_bytes = blob.size();
+  h->finalized = true;
+  return WG_OK;
+}
+
+size_t wg_infer_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames) {
+  if (!h || B < 1 || n_frames < 1) return 0;
+  const int L = n_frames * h->cfg.upsample_stride / h->cfg.n_group;
+  RowGeom g = make_geom(h->cfg, B, L);
+  return carve(h, g, nullptr).bytes;
+}
+
+size_t wg_forward_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
+  if (!h || B < 1 || n_frames < 1 || audio_len < h->cfg.n_group || audio_len % h->cfg.n_group) return 0;
+  RowGeom g = make_geom(h->cfg, B, audio_len / h->cfg.n_group);
+  return carve(h, g, nullptr).bytes;
+}
+
+static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*& cur, _Float16*& oth, hipStream_t s) {
+  const wg_config& c = h->cfg;
+  const int C = c.n_channels;
+  const int BN = wn_block_n(C);
+  const FlowOffsets& fo = h->flows[k];
+  for (int i = 0; i < c.n_layers; ++i) {
+    const LayerOffsets& lo = fo.layers[i];
+    WnLayerArgs a;
+    a.x_in = cur;
+    a.x_out = oth;
+    a.spect = w.S;
+    a.wA1 = (const _Float16*)(h->d_blob + lo.wA1);
+    a.bias1 = (const float*)(h->d_blob + lo.bias1);
+    a.wA2 = (const _Float16*)(h->d_blob + lo.wA2);
+    a.bias2 = (const float*)(h->d_blob + lo.bias2);
+    a.wEs = (const _Float16*)(h->d_blob + lo.wEs);
+    a.out = w.OUT;
+    a.g = g;
+    a.dil = 1 << i;
+    a.ns_chunks = h->NS / 64;
+    a.has_res = i < c.n_layers - 1;
+    a.tiles_per_utt = g.Ltile / BN;
+    a.n_tiles = g.B * a.tiles_per_utt;
+    {
+      Prof p(h, s, 2);
+      HIP_TRY(launch_wn_layer(a, C, s));
+    }
+    if (a.has_res) std::swap(cur, oth);
+  }
+  return WG_OK;
+}
+
+int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* const* z_early, int32_t n_z_early,
+             float sigma, void* audio, int32_t B, int32_t n_frames, int32_t io_dtype, void* workspace,
+             size_t workspace_bytes, void* stream) {
+  if (!h) return fail(WG_ERR_INVALID, "null handle");
+  if (!h->finalized) return fail(WG_ERR_STATE, "wg_finalize has not been called");
+  if (!mel || !z_init || !audio || !workspace) return fail(WG_ERR_INVALID, "null buffer");
+  if (B < 1 || n_frames < 1) return fail(WG_ERR_INVALID, "bad B/n_frames");
+  if (io_dtype != WG_F32 && io_dtype != WG_F16) return fail(WG_ERR_INVALID, "bad io_dtype");
+  const wg_config& c = h->cfg;
+  int n_early = 0;
+  for (int k = 0; k < c.n_flows; ++k) n_early += is_early(c, k);
+  if (n_z_early != n_early || (n_early && !z_early)) return fail(WG_ERR_INVALID, "expected %d early-noise tensors", n_early);
+  const int L = n_frames * c.upsample_stride / c.n_group;
+  if ((int64_t)B * L * 8 >= (1ll << 31)) return fail(WG_ERR_INVALID, "batch too large for 32-bit row indexing");
+  RowGeom g = make_geom(c, B, L);
+  Workspace w = carve(h, g, (char*)workspace);
+  if (w.bytes > workspace_bytes) return fail(WG_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.bytes);
+  if ((size_t)c.n_channels * g.R * 2 >= (1ull << 32)) return fail(WG_ERR_INVALID, "plane too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.n_channels;
+  {
+    Prof p(h, s, 3);
+    // guard rows / rows >= L of both x planes must read as zero padding (model.py:98-102)
+    HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes, s));
+    HIP_TRY(hipMemsetAsync(w.S, 0, w.s_bytes, s));
+  }
+  {
+    UpsampleArgs u;
+    u.mel = mel;
+    u.w = (const float*)(h->d_blob + h->off_upw);
+    u.bias = (const float*)(h->d_blob + h->off_upb);
+    u.spect = w.S;
+    u.g = g;
+    u.M = c.n_mel_channels;
+    u.T = n_frames;
+    u.io_f16 = io_dtype == WG_F16;
+    u.n_q = (8 * L + 255) / 256;
+    Prof p(h, s, 0);
+    HIP_TRY(launch_upsample(u, s));
+  }
+  _Float16 *cur = w.X0, *oth = w.X1;
+  int ze_idx = 0;
+  auto base_flow_args = [&]() {
+    FlowArgs f;
+    memset(&f, 0, sizeof f);
+    f.direction = 0;
+    f.sigma = sigma;
+    f.Z = w.Z;
+    f.out = w.OUT;
+    f.g = g;
+    f.C = C;
+    f.io_f16 = io_dtype == WG_F16;
+    return f;
+  };
+  {
+    const int k = c.n_flows - 1;
+    FlowArgs f = base_flow_args();
+    f.first = 1;
+    f.z_extra = z_init;
+    f.c_next = h->c_k[k];
+    f.h_next = f.c_next / 2;
+    f.wstart = (const float*)(h->d_blob + h->flows[k].wstart);
+    f.bstart = (const float*)(h->d_blob + h->flows[k].bstart);
+    f.out_init = (const float*)(h->d_blob + h->flows[k].out_init);
+    f.x = cur;
+    Prof p(h, s, 1);
+    HIP_TRY(launch_flow(f, s));
+  }
+  for (int k = c.n_flows - 1; k >= 0; --k) {
+    int rc = run_wn(h, k, g, w, cur, oth, s);
+    if (rc) return rc;
+    FlowArgs f = base_flow_args();
+    f.c_in = h->c_k[k];
+    f.h_in = f.c_in / 2;
+    f.winv = (const float*)(h->d_blob + h->flows[k].winv);
+    if (is_early(c, k)) {
+      f.z_extra = z_early[ze_idx++];
+      f.n_extra = c.n_early_size;
+      if (!f.z_extra) return fail(WG_ERR_INVALID, "null early-noise tensor");
+    }
+    f.c_next = f.c_in + f.n_extra;
+    f.last = (k == 0);
+    if (f.last) {
+      if (f.c_next != c.n_group) return fail(WG_ERR_STATE, "flow bookkeeping error");
+      f.audio_out = audio;
+    } else {
+      f.h_next = h->c_k[k - 1] / 2;
+      if (h->c_k[k - 1] != f.c_next) return fail(WG_ERR_STATE, "flow bookkeeping error");
+      f.wstart = (const float*)(h->d_blob + h->flows[k - 1].wstart);
+      f.bstart = (const float*)(h->d_blob + h->flows[k - 1].bstart);
+      f.out_init = (const float*)(h->d_blob + h->flows[k - 1].out_init);
+      f.x = cur;
+    }
+    Prof p(h, s, 1);
+    HIP_TRY(launch_flow(f, s));
+  }
+  return WG_OK;
+}
+
+int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float* const* log_s, float* log_det_W,
+               int32_t B, int32_t n_frames, int32_t audio_len, int32_t io_dtype, void* workspace,
+               size_t workspace_bytes, void* stream) {
+  if (!h) return fail(WG_ERR_INVALID, "null handle");
+  if (!h->finalized) return fail(WG_ERR_STATE, "wg_finalize has not been called");
+  if (!mel || !audio || !z || !log_s || !log_det_W || !workspace) return fail(WG_ERR_INVALID, "null buffer");
+  if (io_dtype != WG_F32 && io_dtype != WG_F16) return fail(WG_ERR_INVALID, "bad io_dtype");
+  const wg_config& c = h->cfg;
+  if (B < 1 || n_frames < 1 || audio_len < c.n_group || audio_len % c.n_group)
+    return fail(WG_ERR_INVALID, "audio_len must be a positive multiple of n_group");
+  // assert spect.size(2) >= audio.size(1)   (model.py:187)
+  if ((int64_t)(n_frames - 1) * c.upsample_stride + c.upsample_kernel < audio_len)
+    return fail(WG_ERR_INVALID, "upsampled mel (%d frames) shorter than audio (%d)", n_frames, audio_len);
+  const int L = audio_len / c.n_group;
+  RowGeom g = make_geom(c, B, L);
+  Workspace w = carve(h, g, (char*)workspace);
+  if (w.bytes > workspace_bytes) return fail(WG_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.n_channels;
+  for (int k = 0; k < c.n_flows; ++k) log_det_W[k] = (float)((double)B * L * h->flows[k].logdet);   // model.py:63
+  HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes, s));
+  HIP_TRY(hipMemsetAsync(w.S, 0, w.s_bytes, s));
+  {
+    UpsampleArgs u;
+    u.mel = mel;
+    u.w = (const float*)(h->d_blob + h->off_upw);
+    u.bias = (const float*)(h->d_blob + h->off_upb);
+    u.spect = w.S;
+    u.g = g;
+    u.M = c.n_mel_channels;
+    u.T = n_frames;
+    u.io_f16 = io_dtype == WG_F16;
+    u.n_q = (8 * L + 255) / 256;
+    Prof p(h, s, 0);
+    HIP_TRY(launch_upsample(u, s));
+  }
+  _Float16 *cur = w.X0, *oth = w.X1;
+  int z_ch = 0;
+  for (int k = 0; k <= c.n_flows; ++k) {
+    FlowArgs f;
+    memset(&f, 0, sizeof f);
+    f.direction = 1;
+    f.Z = w.Z;
+    f.out = w.OUT;
+    f.g = g;
+    f.C = C;
+    f.io_f16 = io_dtype == WG_F16;
+    f.z_out = z;
+    f.z_out_ch0 = z_ch;
+    f.first = (k == 0);
+    f.last = (k == c.n_flows);
+    if (f.first) {
+      f.audio_in = audio;
+      f.c_in = c.n_group;
+    } else {
+      f.c_in = h->c_k[k - 1];
+      f.h_in = f.c_in / 2;
+      f.log_s_out = log_s[k - 1];
+      if (!f.log_s_out) return fail(WG_ERR_INVALID, "null log_s[%d]", k - 1);
+    }
+    if (!f.last) {
+      f.n_peel = is_early(c, k) ? c.n_early_size : 0;
+      f.c_next = h->c_k[k];
+      f.h_next = f.c_next / 2;
+      if (f.c_in - f.n_peel != f.c_next) return fail(WG_ERR_STATE, "flow bookkeeping error");
+      f.winv = (const float*)(h->d_blob + h->flows[k].wfwd);
+      f.wstart = (const float*)(h->d_blob + h->flows[k].wstart);
+      f.bstart = (const float*)(h->d_blob + h->flows[k].bstart);
+      f.out_init = (const float*)(h->d_blob + h->flows[k].out_init);
+      f.x = cur;
+      z_ch += f.n_peel;
+    }
+    {
+      Prof p(h, s, 1);
+      HIP_TRY(launch_flow(f, s));
+    }
+    if (!f.last) {
+      int rc = run_wn(h, k, g, w, cur, oth, s);
+      if (rc) return rc;
+    }
+  }
+  return WG_OK;
+}
+
+double wg_macs_per_group_step(const wg_handle* h) {
+  if (!h) return 0.0;
+  const wg_config& c = h->cfg;
+  const double C = c.n_channels, NS = h->NS, M = c.n_mel_channels;
+  double macs = 8.0 * M * M * 4.0;   // upsample: 8 samples x M x M x 4 taps
+  for (int k = 0; k < c.n_flows; ++k) {
+    const double ck = h->c_k[k], hk = ck / 2;
+    macs += hk * C + NS * 2 * C * c.n_layers + c.n_layers * (C * 2 * C * c.kernel_size) +
+            (c.n_layers - 1) * (C * 2 * C) + C * C + C * 2 * hk + ck * ck;
+  }
+  return macs;
+}
+
+int wg_profile_enable(wg_handle* h, int32_t on) {
+  if (!h) return fail(WG_ERR_INVALID, "null handle");
+  h->prof = on != 0;
+  h->ev_used = 0;
+  for (int i = 0; i < 4; ++i) {
+    h->prof_ms[i] = 0;
+    h->prof_n[i] = 0;
+  }
+  return WG_OK;
+}
+
+int wg_profile_read(wg_handle* h, double* ms, int64_t* n, int32_t n_classes) {
+  if (!h || !ms || !n || n_classes < 4) return fail(WG_ERR_INVALID, "bad argument");
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+    h->prof_ms[h->ev_class[i]] += t;
+    h->prof_n[h->ev_class[i]] += 1;
+  }
+  h->ev_used = 0;
+  for (int i = 0; i < 4; ++i) {
+    ms[i] = h->prof_ms[i];
+    n[i] = h->prof_n[i];
+  }
+  return WG_OK;
+}
+
+}  // extern "C"

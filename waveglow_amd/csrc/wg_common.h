@@ -1,0 +1,112 @@
+// Shared host/device declarations for libwaveglow_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wg {
+
+// ---------------------------------------------------------------------------------------------
+// Channel-position permutation.
+//
+// Activations x (and the gated `acts` tile in LDS) are stored "position-major": within every block
+// of 32 channels, storage position p = 16*h + 4*g + i holds channel 8*g + 4*h + i (g<4, h<2, i<4).
+// That is exactly the order in which one lane of a 32x32 MFMA accumulator holds its 16 rows
+// (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so a lane's 16 results are 32 contiguous bytes of
+// fp16 -- written with two 16-byte stores and read back as MFMA B-operand fragments with
+// ds_read_b128 / global_load_lds, no transpose anywhere.  The GEMM contracts over channels, so the
+// weights are packed with the same permutation on the host and the order cancels.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int pos_to_chan(int P) {
+  const int blk = P >> 5, p = P & 31;
+  const int h = p >> 4, g = (p >> 2) & 3, i = p & 3;
+  return (blk << 5) + 8 * g + 4 * h + i;
+}
+__host__ __device__ inline int chan_to_pos(int c) {
+  const int blk = c >> 5, o = c & 31;
+  const int g = o >> 3, h = (o >> 2) & 1, i = o & 3;
+  return (blk << 5) + 16 * h + 4 * g + i;
+}
+
+constexpr int kMaxGroup = 8;     // n_group (flow state channels)
+constexpr int kBK = 64;          // GEMM K-step (fp16 elements) = one 128-byte row of a chunk plane
+
+// Row geometry of the time-major activation planes.  Every utterance owns Lp rows:
+// G zero guard rows | Ltile rows (L valid, rest never written => zero) | G zero guard rows.
+struct RowGeom {
+  int B;        // utterances
+  int L;        // valid group-timesteps per utterance
+  int Ltile;    // L rounded up to 128
+  int G;        // guard rows each side (>= max dilation)
+  int Lp;       // G + Ltile + G
+  int R;        // B * Lp
+};
+
+struct WnLayerArgs {
+  const _Float16* x_in;     // [C/64][R][64] position-major
+  _Float16* x_out;          // same layout (ping-pong), unused when !has_res
+  const _Float16* spect;    // [NS/64][R][64] natural channel order
+  const _Float16* wA1;      // packed GEMM1 A fragments  [nK][NW][2][4][64][8]
+  const float* bias1;       // [2C]  b_in + b_cond slice
+  const _Float16* wA2;      // packed GEMM2 A fragments  [NW][C/16][64][8]
+  const float* bias2;       // [C]   b_res
+  const _Float16* wEs;      // packed folded end x skip  [C/32][64][8]  (rows 0-7 hi, 8-15 lo)
+  float* out;               // [B*L][8] fp32, accumulated across layers
+  RowGeom g;
+  int dil;                  // dilation of this layer
+  int ns_chunks;            // NS/64 (spect K-steps)
+  int has_res;              // 0 for the last layer of a WN (model.py:106-110)
+  int tiles_per_utt;        // Ltile / BN
+  int n_tiles;              // B * tiles_per_utt
+};
+
+struct UpsampleArgs {
+  const void* mel;          // [B][M][T] io dtype
+  const float* w;           // packed [32][4][M][M*8]  (t', tap j, in-ch i, out ch o*8+g)
+  const float* bias;        // [M]
+  _Float16* spect;          // [NS/64][R][64]
+  RowGeom g;
+  int M, T, io_f16;
+  int n_q;                  // number of output frames q covering 8*L samples: ceil(8L/256)
+};
+
+struct FlowArgs {
+  // direction: 0 = infer (inverse flow, model.py:246-271), 1 = forward (model.py:200-218)
+  int direction;
+  // ---- inverse-flow step (skipped when `first`): coupling of flow k, W^-1 mix, optional early concat
+  int first;                // infer: z = sigma * z_init ; forward: z = squeeze(audio)
+  int c_in;                 // channels of Z on entry
+  int h_in;                 // c_in / 2
+  const float* winv;        // [c_in][c_in] row-major (infer: W^-1 of flow k; forward: W of flow k_next)
+  const void* z_extra;      // infer: z_early[k] [B][n_early][L] io dtype or null; first: z_init [B][c][L]
+  int n_extra;              // channels of z_extra (infer), 0 if none
+  float sigma;
+  // ---- forward-direction extras
+  float* log_s_out;         // forward: [B][h_in][L] fp32 for the flow just finished (or null)
+  float* z_out;             // forward: [B][8][L] fp32 final output
+  int z_out_ch0;            // forward: channel offset in z_out where peeled / final channels go
+  int n_peel;               // forward: channels peeled off before the next flow (model.py:201-203)
+  const void* audio_in;     // forward+first: [B][audio_len] io dtype
+  // ---- next WN start (skipped when `last`)
+  int last;                 // infer: write audio ; forward: write remaining z
+  int c_next;               // channels of Z on exit
+  int h_next;               // c_next / 2
+  const float* wstart;      // [C][h_next] position-major rows (row P <-> channel pos_to_chan(P))
+  const float* bstart;      // [C] position-major
+  const float* out_init;    // [8] folded end bias for the next WN
+  // ---- buffers
+  float* Z;                 // [B*L][8] fp32 flow state (channels-last)
+  float* out;               // [B*L][8] fp32  b | log_s of the flow just computed, re-initialised for next
+  _Float16* x;              // [C/64][R][64] start output
+  void* audio_out;          // infer+last: [B][8L] io dtype
+  RowGeom g;
+  int C;
+  int io_f16;
+};
+
+// launch wrappers (kernels.hip)
+hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
+hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
+hipError_t launch_wn_layer(const WnLayerArgs& a, int C, hipStream_t s);
+int wn_block_n(int C);   // BN used for channel count C
+
+}  // namespace wg

@@ -1,0 +1,257 @@
+"""``WaveGlow`` with the reference's Python surface, computing on the MI355X-native HIP library.
+
+Mirrors src/waveglow/model.py of stefantaubert/waveglow: same constructor argument, same parameter /
+state_dict names and shapes (so ``CheckpointWaveglow.load`` -> ``load_state_dict`` works unchanged, incl.
+the weight-normed 686-key form, the 470-key form after ``remove_weightnorm`` and legacy
+``weight_g``/``weight_v`` keys), same ``infer`` / ``forward`` / ``remove_weightnorm`` signatures.
+
+The torch modules below only HOLD parameters.  All arithmetic of ``infer`` and ``forward`` runs in
+``libwaveglow_amd.so`` (waveglow_amd/csrc) through its C ABI; there is no torch/CPU fallback -- a CPU
+tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from .hparams import HParams
+
+
+class Invertible1x1Conv(nn.Module):
+  """Parameter holder for the invertible 1x1 convolution (model.py:23-43): QR-orthonormal init, det +1."""
+
+  def __init__(self, c: int):
+    super().__init__()
+    self.conv = nn.Conv1d(c, c, kernel_size=1, stride=1, padding=0, bias=False)
+    W = torch.linalg.qr(torch.empty(c, c).normal_())[0]
+    if torch.det(W) < 0:
+      W[:, 0] = -1 * W[:, 0]
+    self.conv.weight.data = W.contiguous().view(c, c, 1)
+
+
+class WN(nn.Module):
+  """Parameter holder for the WaveNet-like coupling network (model.py:75-113)."""
+
+  def __init__(self, n_in_channels: int, n_mel_channels: int, hparams: HParams):
+    super().__init__()
+    assert hparams.kernel_size % 2 == 1
+    assert hparams.n_channels % 2 == 0
+    self.n_layers = hparams.n_layers
+    self.n_channels = hparams.n_channels
+    wn = nn.utils.parametrizations.weight_norm
+    self.in_layers = nn.ModuleList()
+    self.res_skip_layers = nn.ModuleList()
+    self.start = wn(nn.Conv1d(n_in_channels, self.n_channels, 1), name="weight")
+    end = nn.Conv1d(self.n_channels, 2 * n_in_channels, 1)
+    end.weight.data.zero_()   # model.py:90-92
+    end.bias.data.zero_()
+    self.end = end
+    self.cond_layer = wn(nn.Conv1d(n_mel_channels, 2 * self.n_channels * self.n_layers, 1), name="weight")
+    for i in range(self.n_layers):
+      dilation = 2 ** i
+      padding = int((hparams.kernel_size * dilation - dilation) / 2)
+      self.in_layers.append(wn(nn.Conv1d(self.n_channels, 2 * self.n_channels, hparams.kernel_size,
+                                         dilation=dilation, padding=padding), name="weight"))
+      rs = 2 * self.n_channels if i < self.n_layers - 1 else self.n_channels
+      self.res_skip_layers.append(wn(nn.Conv1d(self.n_channels, rs, 1), name="weight"))
+
+
+def _dense_weight(conv: nn.Module) -> torch.Tensor:
+  """``conv.weight`` -- for a weight-normed module this evaluates g*v/||v|| exactly as torch does."""
+  return conv.weight
+
+
+class _Engine:
+  """Owns one wg_handle and the packed device weights derived from a module's parameters."""
+
+  def __init__(self, hp: HParams, device: torch.device):
+    lib = _lib.load()
+    cfg = _lib.WgConfig(hp.n_mel_channels, hp.n_flows, hp.n_group, hp.n_early_every, hp.n_early_size,
+                        hp.n_layers, hp.n_channels, hp.kernel_size, 1024, 256)
+    handle = C.c_void_p()
+    _lib.check(lib.wg_create(C.byref(cfg), device.index if device.index is not None else 0, C.byref(handle)))
+    self.lib = lib
+    self.handle = handle
+    self.device = device
+    self.signature: Optional[tuple] = None
+    self._ws: Dict[Tuple[str, int, int, int], torch.Tensor] = {}
+
+  def __del__(self):
+    try:
+      if getattr(self, "handle", None):
+        self.lib.wg_destroy(self.handle)
+    except Exception:
+      pass
+
+  def upload(self, tensors: Dict[str, torch.Tensor]) -> None:
+    n = self.lib.wg_num_expected_tensors(self.handle)
+    for i in range(n):
+      name = self.lib.wg_expected_tensor_name(self.handle, i).decode()
+      if name not in tensors:
+        raise _lib.WgError(f"missing weight '{name}'")
+      t = tensors[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+      shape = (C.c_int64 * t.dim())(*t.shape)
+      _lib.check(self.lib.wg_set_tensor(self.handle, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+    _lib.check(self.lib.wg_finalize(self.handle))
+
+  def workspace(self, kind: str, nbytes: int, key: Tuple[int, int, int]) -> torch.Tensor:
+    k = (kind,) + key
+    ws = self._ws.get(k)
+    if ws is None or ws.numel() < nbytes:
+      self._ws.clear()
+      ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+      self._ws[k] = ws
+    return ws
+
+
+class WaveGlow(nn.Module):
+  def __init__(self, hparams: HParams):
+    super().__init__()
+    self.upsample = nn.ConvTranspose1d(hparams.n_mel_channels, hparams.n_mel_channels, 1024, stride=256)
+    assert hparams.n_group % 2 == 0
+    self.n_flows = hparams.n_flows
+    self.n_group = hparams.n_group
+    self.n_early_every = hparams.n_early_every
+    self.n_early_size = hparams.n_early_size
+    self.WN = nn.ModuleList()
+    self.convinv = nn.ModuleList()
+    n_half = int(self.n_group / 2)
+    n_remaining_channels = self.n_group
+    for k in range(self.n_flows):
+      if k % self.n_early_every == 0 and k > 0:
+        n_half = n_half - int(self.n_early_size / 2)
+        n_remaining_channels = n_remaining_channels - self.n_early_size
+      self.convinv.append(Invertible1x1Conv(n_remaining_channels))
+      self.WN.append(WN(n_in_channels=n_half, n_mel_channels=hparams.n_mel_channels * self.n_group,
+                        hparams=hparams))
+    self.n_remaining_channels = n_remaining_channels
+    self._hp = hparams
+    self._engine: Optional[_Engine] = None
+
+  # ------------------------------------------------------------------ engine plumbing
+  def dense_state(self) -> Dict[str, torch.Tensor]:
+    """Weight-norm-folded tensors under the 470-key names (what remove_weightnorm would leave)."""
+    out = {"upsample.weight": self.upsample.weight, "upsample.bias": self.upsample.bias}
+    for k in range(self.n_flows):
+      out[f"convinv.{k}.conv.weight"] = self.convinv[k].conv.weight
+      wn, p = self.WN[k], f"WN.{k}."
+      for name, mod in (("start", wn.start), ("cond_layer", wn.cond_layer), ("end", wn.end)):
+        out[p + name + ".weight"] = _dense_weight(mod)
+        out[p + name + ".bias"] = mod.bias
+      for i in range(wn.n_layers):
+        out[p + f"in_layers.{i}.weight"] = _dense_weight(wn.in_layers[i])
+        out[p + f"in_layers.{i}.bias"] = wn.in_layers[i].bias
+        out[p + f"res_skip_layers.{i}.weight"] = _dense_weight(wn.res_skip_layers[i])
+        out[p + f"res_skip_layers.{i}.bias"] = wn.res_skip_layers[i].bias
+    return out
+
+  def _weights_signature(self) -> tuple:
+    return tuple((id(p), p._version, p.data_ptr()) for p in self.parameters())
+
+  def _get_engine(self, device: torch.device) -> _Engine:
+    if device.type != "cuda":
+      raise _lib.WgError("waveglow_amd runs on MI355X only: move the model and inputs to a 'cuda' (ROCm) device; "
+                         "there is no CPU fallback")
+    if self._engine is None or self._engine.device != device:
+      self._engine = _Engine(self._hp, device)
+    sig = self._weights_signature()
+    if self._engine.signature != sig:
+      # W^-1 and every packed layout are derived state keyed on the parameter versions
+      # (the reference caches W_inverse as a plain attribute and goes stale: model.py:52-58)
+      with torch.no_grad():
+        self._engine.upload(self.dense_state())
+      self._engine.signature = sig
+    return self._engine
+
+  @staticmethod
+  def _io_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+      return _lib.WG_F32
+    if t.dtype == torch.float16:
+      return _lib.WG_F16
+    raise _lib.WgError(f"unsupported dtype {t.dtype} (float32 or float16)")
+
+  # ------------------------------------------------------------------ reference API
+  def infer_with_noise(self, spect: torch.Tensor, z_init: torch.Tensor, z_early: List[torch.Tensor],
+                       sigma: float = 1.0) -> torch.Tensor:
+    """``infer`` with the three noise draws injected (z_early in descending flow order)."""
+    eng = self._get_engine(spect.device)
+    io = self._io_dtype(spect)
+    spect = spect.contiguous()
+    B, M, T = spect.shape
+    L = T * 256 // self.n_group
+    assert z_init.shape == (B, self.n_remaining_channels, L) and z_init.dtype == spect.dtype
+    z_init = z_init.contiguous()
+    z_early = [z.contiguous() for z in z_early]
+    for z in z_early:
+      assert z.shape == (B, self.n_early_size, L) and z.dtype == spect.dtype and z.device == spect.device
+    audio = torch.empty((B, T * 256), dtype=spect.dtype, device=spect.device)
+    nbytes = eng.lib.wg_infer_workspace_bytes(eng.handle, B, T)
+    ws = eng.workspace("infer", nbytes, (B, T, 0))
+    ze = (C.c_void_p * max(1, len(z_early)))(*[z.data_ptr() for z in z_early])
+    stream = torch.cuda.current_stream(spect.device).cuda_stream
+    _lib.check(eng.lib.wg_infer(eng.handle, spect.data_ptr(), z_init.data_ptr(), ze, len(z_early), float(sigma),
+                                audio.data_ptr(), B, T, io, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+    return audio
+
+  def infer(self, spect: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
+    """model.py:223-274.  Noise is drawn with the device RNG in the tensor dtype, in the reference's
+    order: [B,n_rem,L], then [B,n_early,L] per early-output flow for descending k."""
+    B, _, T = spect.shape
+    L = T * 256 // self.n_group
+    z_init = torch.empty((B, self.n_remaining_channels, L), dtype=spect.dtype, device=spect.device).normal_()
+    z_early = []
+    for k in reversed(range(self.n_flows)):
+      if k % self.n_early_every == 0 and k > 0:
+        z_early.append(torch.empty((B, self.n_early_size, L), dtype=spect.dtype, device=spect.device).normal_())
+    return self.infer_with_noise(spect, z_init, z_early, sigma)
+
+  def forward(self, forward_input):
+    """model.py:178-221: (mel [B,M,F], audio [B,S]) -> (z [B,8,L], [log_s_k], [log_det_W_k]).
+    Normalising direction without autograd (the backward pass is not part of this round)."""
+    spect, audio = forward_input
+    eng = self._get_engine(spect.device)
+    io = self._io_dtype(spect)
+    assert audio.dtype == spect.dtype and audio.device == spect.device
+    spect, audio = spect.contiguous(), audio.contiguous()
+    B, M, F_ = spect.shape
+    S = audio.shape[1]
+    assert (F_ - 1) * 256 + 1024 >= S   # model.py:187
+    S = S - S % self.n_group            # unfold drops the remainder (model.py:191,195)
+    if S != audio.shape[1]:
+      audio = audio[:, :S].contiguous()
+    L = S // self.n_group
+    z = torch.empty((B, self.n_group, L), dtype=torch.float32, device=spect.device)
+    log_s, c = [], self.n_group
+    for k in range(self.n_flows):
+      if k % self.n_early_every == 0 and k > 0:
+        c -= self.n_early_size
+      log_s.append(torch.empty((B, c // 2, L), dtype=torch.float32, device=spect.device))
+    log_det = (C.c_float * self.n_flows)()
+    nbytes = eng.lib.wg_forward_workspace_bytes(eng.handle, B, F_, S)
+    ws = eng.workspace("fwd", nbytes, (B, F_, S))
+    ls = (C.c_void_p * self.n_flows)(*[t.data_ptr() for t in log_s])
+    stream = torch.cuda.current_stream(spect.device).cuda_stream
+    _lib.check(eng.lib.wg_forward(eng.handle, spect.data_ptr(), audio.data_ptr(), z.data_ptr(), ls, log_det,
+                                  B, F_, S, io, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+    log_det_list = [torch.tensor(log_det[k], dtype=torch.float32, device=spect.device) for k in range(self.n_flows)]
+    if spect.dtype != torch.float32:
+      z = z.to(spect.dtype)
+      log_s = [t.to(spect.dtype) for t in log_s]
+    return z, log_s, log_det_list
+
+  @staticmethod
+  def remove_weightnorm(model: "WaveGlow") -> "WaveGlow":
+    """model.py:276-297: materialise w = g*v/||v|| for start, cond_layer, in_layers, res_skip_layers."""
+    rp = nn.utils.parametrize.remove_parametrizations
+    for wnet in model.WN:
+      if nn.utils.parametrize.is_parametrized(wnet.start, "weight"):
+        wnet.start = rp(wnet.start, "weight")
+        wnet.cond_layer = rp(wnet.cond_layer, "weight")
+        wnet.in_layers = nn.ModuleList([rp(m, "weight") for m in wnet.in_layers])
+        wnet.res_skip_layers = nn.ModuleList([rp(m, "weight") for m in wnet.res_skip_layers])
+    return model
