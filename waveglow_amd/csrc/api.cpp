@@ -80,6 +80,10 @@ bool invert(const std::vector<double>& A, int n, std::vector<double>& inv, doubl
   return true;
 }
 
+// tanh(a) = 1 - 2/(1 + 2^(a*kTanhScale)), sigmoid(b) = 1/(1 + 2^(b*kSigmScale)): folded into GEMM-1 rows
+constexpr float kTanhScale = 2.8853900817779268f;    // 2*log2(e)
+constexpr float kSigmScale = -1.4426950408889634f;   // -log2(e)
+
 struct LayerOffsets {
   size_t wA1, bias1, wA2, bias2, wEs;
 };
@@ -205,8 +209,8 @@ int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
   if (c.n_layers < 1 || c.n_layers > 8) return fail(WG_ERR_INVALID, "n_layers=%d unsupported (1..8)", c.n_layers);
   if (c.upsample_kernel != 1024 || c.upsample_stride != 256)
     return fail(WG_ERR_INVALID, "upsample geometry %d/%d unsupported (1024/256)", c.upsample_kernel, c.upsample_stride);
-  if (c.n_mel_channels < 1 || c.n_mel_channels > 80 || (c.n_mel_channels * c.n_group) % 64 != 0)
-    return fail(WG_ERR_INVALID, "n_mel_channels=%d unsupported (multiple of 8, <= 80)", c.n_mel_channels);
+  if (c.n_mel_channels < 16 || c.n_mel_channels > 80 || c.n_mel_channels % 16 != 0)
+    return fail(WG_ERR_INVALID, "n_mel_channels=%d unsupported (multiple of 16, <= 80)", c.n_mel_channels);
   if (c.n_flows < 1 || c.n_early_every < 1 || c.n_early_size < 0 || c.n_early_size % 2 != 0)
     return fail(WG_ERR_INVALID, "bad flow configuration");
   std::vector<int> ck = flow_channels(c);
@@ -289,7 +293,7 @@ int wg_finalize(wg_handle* h) {
   if (!h) return fail(WG_ERR_INVALID, "null handle");
   const wg_config& c = h->cfg;
   const int C = c.n_channels, M = c.n_mel_channels, NS = h->NS, NL = c.n_layers;
-  const int NW = C / 32, CC = C / 64, K2 = C / 16, nK = 3 * CC + NS / 64;
+  const int NW = wn_waves(C), MB = C / (32 * NW), MT = 2 * MB, CC = C / 64, K2 = C / 16, nK = 3 * CC + NS / 64;
   std::vector<char> blob;
   auto reserve = [&](size_t bytes) {
     size_t off = align_up(blob.size());
@@ -302,16 +306,23 @@ int wg_finalize(wg_handle* h) {
   if ((rc = check_shape(h, "upsample.weight", {M, M, c.upsample_kernel}, &upw))) return rc;
   if ((rc = check_shape(h, "upsample.bias", {M}, &upb))) return rc;
   {
-    const int NCH = M * 8;
-    h->off_upw = reserve((size_t)32 * 4 * M * NCH * 4);
-    float* wp = (float*)(blob.data() + h->off_upw);
+    // A fragments [32 t'][NS/64 cs][2 mb][M/4 k16][64 lanes][8]: row r of block (cs,mb) is channel
+    // ch = cs*64 + mb*32 + r = o*8+g; k = j*M + i  <->  W[i][o][8t'+g+256j]
+    const int NSC = M / 8, KS = M / 4, KPJ = M / 16;
+    h->off_upw = reserve((size_t)32 * NSC * 2 * KS * 64 * 8 * 2);
+    _Float16* wp = (_Float16*)(blob.data() + h->off_upw);
     for (int tp = 0; tp < 32; ++tp)
-      for (int j = 0; j < 4; ++j)
-        for (int i = 0; i < M; ++i)
-          for (int o = 0; o < M; ++o)
-            for (int g = 0; g < 8; ++g)
-              wp[(((size_t)tp * 4 + j) * M + i) * NCH + o * 8 + g] =
-                  upw->data[((size_t)i * M + o) * c.upsample_kernel + 8 * tp + g + 256 * j];
+      for (int cs = 0; cs < NSC; ++cs)
+        for (int mb = 0; mb < 2; ++mb)
+          for (int k = 0; k < KS; ++k)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int r = lane & 31, hh = lane >> 5;
+              const int ch = cs * 64 + mb * 32 + r, o = ch >> 3, g = ch & 7;
+              const int j = k / KPJ, i0 = (k % KPJ) * 16 + 8 * hh;
+              _Float16* d = wp + ((((size_t)(tp * NSC + cs) * 2 + mb) * KS + k) * 64 + lane) * 8;
+              for (int e = 0; e < 8; ++e)
+                d[e] = (_Float16)upw->data[((size_t)(i0 + e) * M + o) * c.upsample_kernel + 8 * tp + g + 256 * j];
+            }
     h->off_upb = reserve((size_t)M * 4);
     memcpy(blob.data() + h->off_upb, upb->data.data(), (size_t)M * 4);
   }
@@ -372,18 +383,22 @@ int wg_finalize(wg_handle* h) {
       if ((rc = check_shape(h, p + "in_layers." + is + ".bias", {2 * C}, &bin))) return rc;
       if ((rc = check_shape(h, p + "res_skip_layers." + is + ".weight", {RS, C, 1}, &wrs))) return rc;
       if ((rc = check_shape(h, p + "res_skip_layers." + is + ".bias", {RS}, &brs))) return rc;
-      // GEMM1 A fragments [nK][NW][2][4][64][8]
-      lo.wA1 = reserve((size_t)nK * NW * 8 * 64 * 8 * 2);
+      // GEMM1 A fragments [2*nK half K-steps][NW][MT][2 k16][64 lanes][8]; wave w owns 32-channel blocks
+      // w*MB .. w*MB+MB-1: M-tiles mt < MB are their tanh rows, mt >= MB their sigmoid rows (+C)
+      lo.wA1 = reserve((size_t)nK * 2 * NW * MT * 2 * 64 * 8 * 2);
       {
         _Float16* dst = (_Float16*)(blob.data() + lo.wA1);
-        for (int ksx = 0; ksx < nK; ++ksx)
+        for (int u = 0; u < 2 * nK; ++u)
           for (int w = 0; w < NW; ++w)
-            for (int mt = 0; mt < 2; ++mt)
-              for (int k16 = 0; k16 < 4; ++k16)
+            for (int mt = 0; mt < MT; ++mt)
+              for (int k2 = 0; k2 < 2; ++k2)
                 for (int lane = 0; lane < 64; ++lane) {
+                  const int ksx = u >> 1, k16 = (u & 1) * 2 + k2;
                   const int r = lane & 31, hh = lane >> 5;
-                  const int m = mt * C + 32 * w + r;
-                  _Float16* d = dst + (((((size_t)ksx * NW + w) * 2 + mt) * 4 + k16) * 64 + lane) * 8;
+                  const bool tanh_row = mt < MB;
+                  const int m = (tanh_row ? 0 : C) + 32 * (w * MB + (tanh_row ? mt : mt - MB)) + r;
+                  const float rs = tanh_row ? kTanhScale : kSigmScale;   // gate pre-scale (kernels.hip gate_act)
+                  _Float16* d = dst + (((((size_t)u * NW + w) * MT + mt) * 2 + k2) * 64 + lane) * 8;
                   for (int j = 0; j < 8; ++j) {
                     const int kk = k16 * 16 + 8 * hh + j;
                     float v;
@@ -392,34 +407,36 @@ int wg_finalize(wg_handle* h) {
                       const int ch = pos_to_chan(cc * 64 + kk);
                       v = win->data[((size_t)m * C + ch) * 3 + tap];
                     } else {
-                      const int s = (ksx - 3 * CC) * 64 + kk;
-                      v = wcond->data[((size_t)(2 * C * i + m)) * NS + s];
+                      const int sch = pos_to_chan((ksx - 3 * CC) * 64 + kk);   // spect planes are position-major too
+                      v = wcond->data[((size_t)(2 * C * i + m)) * NS + sch];
                     }
-                    d[j] = (_Float16)v;
+                    d[j] = (_Float16)(v * rs);
                   }
                 }
       }
       lo.bias1 = reserve((size_t)2 * C * 4);
       {
         float* b1 = (float*)(blob.data() + lo.bias1);
-        for (int m = 0; m < 2 * C; ++m) b1[m] = bin->data[m] + bcond->data[2 * C * i + m];
+        for (int m = 0; m < 2 * C; ++m)
+          b1[m] = (bin->data[m] + bcond->data[2 * C * i + m]) * (m < C ? kTanhScale : kSigmScale);
       }
-      // GEMM2 (res) A fragments [NW][K2][64][8], bias2
-      lo.wA2 = reserve((size_t)NW * K2 * 64 * 8 * 2);
+      // GEMM2 (res) A fragments [NW][MB][K2][64][8], bias2
+      lo.wA2 = reserve((size_t)NW * MB * K2 * 64 * 8 * 2);
       lo.bias2 = reserve((size_t)C * 4);
       if (has_res) {
         _Float16* dst = (_Float16*)(blob.data() + lo.wA2);
         for (int w = 0; w < NW; ++w)
-          for (int k16 = 0; k16 < K2; ++k16)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int r = lane & 31, hh = lane >> 5;
-              const int m = 32 * w + r;
-              _Float16* d = dst + (((size_t)w * K2 + k16) * 64 + lane) * 8;
-              for (int j = 0; j < 8; ++j) {
-                const int ch = pos_to_chan(k16 * 16 + 8 * hh + j);
-                d[j] = (_Float16)wrs->data[(size_t)m * C + ch];
+          for (int mb = 0; mb < MB; ++mb)
+            for (int k16 = 0; k16 < K2; ++k16)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 31, hh = lane >> 5;
+                const int m = 32 * (w * MB + mb) + r;
+                _Float16* d = dst + ((((size_t)w * MB + mb) * K2 + k16) * 64 + lane) * 8;
+                for (int j = 0; j < 8; ++j) {
+                  const int ch = pos_to_chan(k16 * 16 + 8 * hh + j);
+                  d[j] = (_Float16)wrs->data[(size_t)m * C + ch];
+                }
               }
-            }
         float* b2 = (float*)(blob.data() + lo.bias2);
         for (int m = 0; m < C; ++m) b2[m] = brs->data[m];
       }
@@ -543,7 +560,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
   {
     UpsampleArgs u;
     u.mel = mel;
-    u.w = (const float*)(h->d_blob + h->off_upw);
+    u.w = (const _Float16*)(h->d_blob + h->off_upw);
     u.bias = (const float*)(h->d_blob + h->off_upb);
     u.spect = w.S;
     u.g = g;
@@ -638,7 +655,7 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   {
     UpsampleArgs u;
     u.mel = mel;
-    u.w = (const float*)(h->d_blob + h->off_upw);
+    u.w = (const _Float16*)(h->d_blob + h->off_upw);
     u.bias = (const float*)(h->d_blob + h->off_upb);
     u.spect = w.S;
     u.g = g;

@@ -27,30 +27,68 @@ __device__ __forceinline__ float load_io(const void* p, size_t i, int f16) {
   return f16 ? (float)((const _Float16*)p)[i] : ((const float*)p)[i];
 }
 
-// tanh(a) * sigmoid(b)  (model.py:17-19) with one reciprocal: (e^{2a}-1) / ((e^{2a}+1)(1+e^{-b}))
-__device__ __forceinline__ float gate_act(float a, float b) {
-  a = fminf(fmaxf(a, -15.0f), 15.0f);
-  const float e2a = __expf(2.0f * a);
-  const float emb = __expf(-b);
-  return (e2a - 1.0f) * __builtin_amdgcn_rcpf((e2a + 1.0f) * (1.0f + emb));
+// tanh(a) * sigmoid(b)  (model.py:17-19).  The host pre-scales the tanh rows of the GEMM-1 weights/bias by
+// 2*log2(e) and the sigmoid rows by -log2(e), so with u = 2a*log2e, v = -b*log2e:
+//   tanh(a) = 1 - 2/(1 + 2^u),  sigmoid(b) = 1/(1 + 2^v)      (saturates correctly at 2^u, 2^v = 0 or inf)
+__device__ __forceinline__ float gate_act(float u, float v) {
+  const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+  const float r2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v));
+  return fmaf(-2.0f, r1, 1.0f) * r2;
+}
+
+// ---- hand-counted VMEM in the GEMM main loop (cdna_hip_programming.md 5.7): hipcc drains an LDS-DMA before
+// any later LDS read and sinks register loads next to their use; both serialise the K loop on memory latency.
+// These loads are invisible to the compiler's s_waitcnt bookkeeping; every consumer sits behind wait_vm0*.
+// LDS-DMA: 64 lanes x 16 B from (sbase + voff) to LDS [lds_addr + lane*16] (M0 saved/restored in-statement).
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void gload16(half8& dst, const void* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
 }
 
 // =============================================================================================
 // WN layer
 // =============================================================================================
 template <int C> struct WnCfg {
-  static constexpr int BN = (C >= 512) ? 64 : 128;
+  static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
+  static constexpr int BN = (C >= 512) ? 64 : 128;     // columns (group-timesteps) per workgroup
 };
 
-template <int C, int BN>
-__global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerArgs a) {
-  constexpr int NW = C / 32;             // waves: wave w owns gate channels [32w, 32w+32)
+// "wait until at most N VMEM ops are outstanding" for the hand-issued loads.  Deliberately NOT tied to the
+// destination registers: a "+v" tie lets the register allocator copy a fragment BEFORE the wait (observed:
+// v_mov of in-flight registers).  Order is pinned instead by the sched_barrier(0) that follows every wait and
+// precedes every MFMA group (cdna_hip_programming.md 5.7 form (iii), 5.4 rule 18).
+template <int N> __device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One WN layer for one tile of BN group-timesteps of one utterance.
+//   GEMM 1  [2C x (3C + NS)] . [(3C + NS) x BN]: the three dilated taps of in_layers[i] and the layer's slice of
+//           cond_layer as ONE K-extended MFMA GEMM (the [B,16C,L] cond tensor of model.py:121 never exists).
+//   gate    tanh * sigmoid in the accumulator registers (model.py:13-20) -> fp16 acts tile in LDS.
+//   GEMM 2  res rows of res_skip_layers[i] . acts, accumulated onto x (model.py:130-132) -> x_out.
+//   GEMM 3  (W_end . W_skip_i) . acts, 8 rows: the skip path folded through WN.end (model.py:133-137), added to out.
+// Wave w owns gate channels [32*MB*w, 32*MB*(w+1)): its A (weight) fragments are private, so they go L2 -> VGPR
+// directly (pre-packed in fragment order, 1 KiB per wave-load); the B tile (activations) is shared by all waves
+// and goes HBM/L2 -> LDS by LDS-DMA.  All VMEM of the K loop is hand-counted (see glds16).
+template <int C, int NW, int BN>
+__global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
+  constexpr int MB = C / (32 * NW);      // 32-channel blocks per wave
+  constexpr int MT = 2 * MB;             // M tiles per wave: MB tanh blocks, then MB sigmoid blocks
   constexpr int NTHREADS = NW * 64;
   constexpr int NT = BN / 32;            // 32-column MFMA tiles per wave
   constexpr int CC = C / 64;             // 64-channel chunks of x
   constexpr int BT_BYTES = BN * 128;     // one staged B tile: BN rows x 64 fp16
   constexpr int ACT_ROW = 2 * C;         // bytes per acts row
   constexpr int K2 = C / 16;             // k16 steps of GEMM2
+  constexpr int NG = BN * 8 / NTHREADS;  // LDS-DMA instructions per wave per B tile
+  constexpr int NAH = MT * 2;            // A-fragment loads per half K-step
+  static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2, "tile geometry");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sB = smem;                     // 2 x BT_BYTES
@@ -87,18 +125,22 @@ __global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerAr
     return (const char*)(a.spect + ((size_t)cs * R + r0) * 64);
   };
   // LDS-DMA one B tile: piece idx = row*8 + physical 16-B chunk; logical chunk = phys ^ ((row>>1)&7)
-  auto stage_B = [&](int ks, char* dst) {
+  // (LDS destination is lane-linear, so the bank swizzle is applied to the SOURCE address).
+  // Per-lane source offsets are the same for every K-step; only the scalar tile base moves.
+  unsigned pvoff[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int idx = i * NTHREADS + tid;
+    const int row = idx >> 3, pc = idx & 7;
+    pvoff[i] = row * 128 + ((pc ^ ((row >> 1) & 7)) << 4);
+  }
+  const unsigned sB_addr = (unsigned)(size_t)WG_LPTR(sB);
+  auto stage_B = [&](int ks, int bufsel) {
     const char* src = kstep_src(ks);
 #pragma unroll
-    for (int i0 = 0; i0 < BN * 8; i0 += NTHREADS) {
-      const int base = i0 + wave * 64;
-      if (base < BN * 8) {
-        const int idx = base + lane;
-        const int row = idx >> 3, pc = idx & 7;
-        const char* g = src + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4);
-        __builtin_amdgcn_global_load_lds(WG_GPTR(g), WG_LPTR(dst + base * 16), 16, 0, 0);
-      }
-    }
+    for (int i = 0; i < NG; ++i)
+      glds16(src, pvoff[i],
+             __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16));
   };
   const int swB = (ln >> 1) & 7;
   auto read_B = [&](const char* buf, int nt, int k16) -> half8 {
@@ -106,21 +148,30 @@ __global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerAr
     const int c = (k16 * 2 + lh) ^ swB;
     return *(const half8*)(buf + n * 128 + c * 16);
   };
-  const half8* const wA1 = (const half8*)a.wA1;
-  auto load_A = [&](int ks, half8 (&dst)[2][4]) {
-    const half8* p = wA1 + ((size_t)(ks * NW + wave) * 8) * 64 + lane;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dst[mt][k] = p[(mt * 4 + k) * 64];
+  // A fragments of half K-step u (= 2*ks + half): [u][wave][MT][2 k16][64 lanes][8], MT*2 KiB per wave
+  const unsigned a_voff = lane * 16;
+  auto load_Ah = [&](int u, half8 (&dst)[MT][2]) {
+    const char* p = (const char*)a.wA1 + ((size_t)u * NW + wave) * (NAH * 1024);   // wave-uniform
+    gload16<0>(dst[0][0], p, a_voff);
+    gload16<1024>(dst[0][1], p, a_voff);
+    gload16<2048>(dst[1][0], p, a_voff);
+    gload16<3072>(dst[1][1], p, a_voff);
+    if constexpr (MT == 4) {
+      const char* p2 = p + 4096;
+      gload16<0>(dst[2][0], p2, a_voff);
+      gload16<1024>(dst[2][1], p2, a_voff);
+      gload16<2048>(dst[3][0], p2, a_voff);
+      gload16<3072>(dst[3][1], p2, a_voff);
+    }
   };
 
-  // ---- GEMM1 accumulators, initialised with the bias (in_layer bias + cond bias slice)
-  f32x16 acc[2][NT];
+  // ---- GEMM1 accumulators, initialised with the (pre-scaled) bias: in_layer bias + cond bias slice
+  f32x16 acc[MT][NT];
   {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float* bp = a.bias1 + mt * C + wave * 32 + 4 * lh;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row0 = (mt < MB ? 0 : C) + (wave * MB + (mt < MB ? mt : mt - MB)) * 32;
+      const float* bp = a.bias1 + row0 + 4 * lh;
       f32x16 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = bp[(r & 3) + 8 * (r >> 2)];
@@ -129,83 +180,115 @@ __global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerAr
     }
   }
 
-  half8 aA[2][4], aB[2][4];
-  stage_B(0, sB);
-  load_A(0, aA);
-
-  auto compute = [&](const char* buf, half8 (&af)[2][4]) {
+  // ---- K loop.  Invariant at the top of step ks: tile ks is visible in LDS buffer ks&1, h0 = A(2ks) is
+  // in registers, h1 = A(2ks+1) is in flight.  Queue order lets every wait be a counted vmcnt:
+  //   [h1] glds(ks+1) | k16 0,1 on h0 | load h0 <- A(2ks+2) | wait h1: vmcnt(NG+NAH) | k16 2,3 on h1 |
+  //   load h1 <- A(2ks+3) | vmcnt(NAH): h0 and the DMA landed | ONE s_barrier per K-step.
+  // B fragments are read one k16 step ahead of their MFMAs (double-buffered in registers).
+  half8 h0[MT][2], h1[MT][2];
+  stage_B(0, 0);
+  load_Ah(0, h0);
+  load_Ah(1, h1);
+  wait_vm<NAH>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ks = 0; ks < nK; ++ks) {
+    const char* buf = sB + (ks & 1) * BT_BYTES;
+    const bool more = ks + 1 < nK;          // wave-uniform
+    if (more) stage_B(ks + 1, (ks + 1) & 1);
+    half8 bf[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      half8 bf[NT];
+      if (k < 3) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = read_B(buf, nt, k);
+        for (int nt = 0; nt < NT; ++nt) bf[(k + 1) & 1][nt] = read_B(buf, nt, k + 1);
+      }
+      if (k == 2) {
+        if (more) wait_vm<NG + NAH>(); else wait_vm<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? h0[mt][k & 1] : h1[mt][k & 1],
+                                                               bf[k & 1][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k == 1 && more) load_Ah(2 * ks + 2, h0);
+      if (k == 3 && more) load_Ah(2 * ks + 3, h1);
+    }
+    if (more) {
+      wait_vm<NAH>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- issue the loads the post-gate phases need now, so their latency hides under the gate's VALU work:
+  // residual input x (this tile, this wave's channels: lane (n, h) owns positions [32*blk + 16h, +16) of
+  // column n = 32 contiguous bytes) and the first GEMM2 weight fragments.
+  constexpr int PF = 8;                     // GEMM2 A-fragment prefetch depth
+  half8 xres[MB][NT][2];
+  half8 a2[MB][PF];
+  const half8* const p2 = (const half8*)a.wA2 + (size_t)wave * MB * K2 * 64 + lane;
+  if (a.has_res) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int blk = wave * MB + mb;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][k], bf[nt], acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][k], bf[nt], acc[1][nt], 0, 0, 0);
+        const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + ln;
+        const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lh * 16);
+        xres[mb][nt][0] = xp[0];
+        xres[mb][nt][1] = xp[1];
       }
-    }
-  };
-
-  // Two K-steps per trip so the A-fragment double buffer needs no register copies.
-  int ks = 0;
-  for (; ks + 1 < nK; ks += 2) {
-    __syncthreads();                       // tile ks landed (vmcnt(0) + barrier); buffer 1 free
-    stage_B(ks + 1, sB + BT_BYTES);
-    load_A(ks + 1, aB);
-    compute(sB, aA);
-    __syncthreads();                       // tile ks+1 landed; buffer 0 free
-    if (ks + 2 < nK) {
-      stage_B(ks + 2, sB);
-      load_A(ks + 2, aA);
-    }
-    compute(sB + BT_BYTES, aB);
-  }
-  if (ks < nK) {                           // odd nK tail
-    __syncthreads();
-    compute(sB, aA);
-  }
-
-  // ---- residual input (x at this tile, this wave's 32 channels) -> GEMM2 accumulator init
-  // Lane (n, h) owns positions [32w+16h, +16) of column n: 32 contiguous bytes.
-  constexpr int cc_w_shift = 1;            // two waves per 64-channel chunk
-  f32x16 acc2[NT];
-  const int my_cc = wave >> cc_w_shift;
-  const int my_off = (wave & 1) * 32 + lh * 16;          // fp16 elements inside the 64-wide row
-  if (a.has_res) {
-    const float* bp = a.bias2 + wave * 32 + 4 * lh;
-    float bv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const size_t row = (size_t)my_cc * R + r0 + nt * 32 + ln;
-      const half8* xp = (const half8*)(a.x_in + row * 64 + my_off);
-      const half8 x0 = xp[0], x1 = xp[1];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        acc2[nt][r] = (float)x0[r] + bv[r];
-        acc2[nt][8 + r] = (float)x1[r] + bv[8 + r];
-      }
+      for (int i = 0; i < PF; ++i) a2[mb][i] = p2[((size_t)mb * K2 + i) * 64];
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- gate (model.py:13-20) in registers; acts -> LDS as fp16, position-major, XOR-swizzled
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    half8 o0, o1;
+  for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      o0[r] = (_Float16)gate_act(acc[0][nt][r], acc[1][nt][r]);
-      o1[r] = (_Float16)gate_act(acc[0][nt][8 + r], acc[1][nt][8 + r]);
+    for (int nt = 0; nt < NT; ++nt) {
+      half8 o0, o1;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        o0[r] = (_Float16)gate_act(acc[mb][nt][r], acc[MB + mb][nt][r]);
+        o1[r] = (_Float16)gate_act(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r]);
+      }
+      const int n = nt * 32 + ln;
+      const int sw = (ACT_ROW >= 256) ? (n & 15) : ((n >> 1) & 7);
+      const int c0 = (wave * MB + mb) * 4 + lh * 2;
+      *(half8*)(sActs + n * ACT_ROW + ((c0 ^ sw) << 4)) = o0;
+      *(half8*)(sActs + n * ACT_ROW + (((c0 + 1) ^ sw) << 4)) = o1;
     }
-    const int n = nt * 32 + ln;
-    const int sw = (ACT_ROW >= 256) ? (n & 15) : ((n >> 1) & 7);
-    const int c0 = wave * 4 + lh * 2;
-    *(half8*)(sActs + n * ACT_ROW + ((c0 ^ sw) << 4)) = o0;
-    *(half8*)(sActs + n * ACT_ROW + (((c0 + 1) ^ sw) << 4)) = o1;
   }
   __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // GEMM2 accumulators start from x + b_res (residual add for free, model.py:132)
+  f32x16 acc2[MB][NT];
+  if (a.has_res) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float* bp = a.bias2 + (wave * MB + mb) * 32 + 4 * lh;
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          acc2[mb][nt][r] = (float)xres[mb][nt][0][r] + bv[r];
+          acc2[mb][nt][8 + r] = (float)xres[mb][nt][1][r] + bv[8 + r];
+        }
+    }
+  }
 
   auto read_acts32 = [&](int nt, int k16) -> half8 {       // B fragment for the 32x32x16 MFMA
     const int n = nt * 32 + ln;
@@ -213,44 +296,61 @@ __global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerAr
     return *(const half8*)(sActs + n * ACT_ROW + (((k16 * 2 + lh) ^ sw) << 4));
   };
 
-  // ---- GEMM2: res rows of this wave (model.py:130-132)
-  if (a.has_res) {
-    const half8* p2 = (const half8*)a.wA2 + (size_t)wave * K2 * 64 + lane;
-    constexpr int PF = 4;
-    half8 a2[PF];
+  // ---- folded end x skip, part 1: issue the weight-fragment and out loads now, consume after GEMM2
+  const int l15 = lane & 15, l4 = lane >> 4;
+  constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
+  half8 wes[C / 32];
+  {
+    const half8* pe = (const half8*)a.wEs + lane;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) a2[i] = p2[i * 64];
+    for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
+  }
+
+  // ---- GEMM2: res rows of this wave (model.py:130-132); acts fragments read one k16 step ahead
+  if (a.has_res) {
+    half8 bq[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bq[0][nt] = read_acts32(nt, 0);
 #pragma unroll
     for (int k = 0; k < K2; ++k) {
-      const half8 af = a2[k % PF];
-      if (k + PF < K2) a2[k % PF] = p2[(k + PF) * 64];
+      if (k + 1 < K2) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, read_acts32(nt, k), acc2[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) bq[(k + 1) & 1][nt] = read_acts32(nt, k + 1);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const half8 af = a2[mb][k % PF];
+        if (k + PF < K2) a2[mb][k % PF] = p2[((size_t)mb * K2 + k + PF) * 64];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc2[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[k & 1][nt], acc2[mb][nt], 0, 0, 0);
+      }
     }
   }
 
   // ---- folded end x skip (model.py:133-137): out[0:8] += (W_end W_skip_i) acts, 16 columns per group,
   // weights split hi+lo fp16 (rows 0-7 / 8-15 of the 16x16x32 MFMA) so the 8 flow outputs keep ~fp32 weights.
-  {
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const half8* pe = (const half8*)a.wEs + lane;
-    for (int grp = wave; grp < BN / 16; grp += NW) {
+#pragma unroll
+  for (int gi = 0; gi < NGRP; ++gi) {
+    const int grp = wave + gi * NW;
+    if (grp < BN / 16) {
       const int n = grp * 16 + l15;
+      const int t = t0 + n;
+      const bool valid = lane < 32 && t < a.g.L;
+      float4* op = (float4*)(a.out + ((size_t)b * a.g.L + t) * 8 + 4 * l4);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) o = *op;
       const int sw = (ACT_ROW >= 256) ? (n & 15) : ((n >> 1) & 7);
       f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C / 32; ++s) {
-        const half8 bf = *(const half8*)(sActs + n * ACT_ROW + (((s * 4 + l4) ^ sw) << 4));
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(pe[s * 64], bf, d, 0, 0, 0);
+        const half8 bfe = *(const half8*)(sActs + n * ACT_ROW + (((s * 4 + l4) ^ sw) << 4));
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wes[s], bfe, d, 0, 0, 0);
       }
       // D: col = lane&15, row = 4*(lane>>4)+reg ; rows 8-15 (lanes 32-63) are the lo parts
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[r] += __shfl_xor(d[r], 32);
-      const int t = t0 + n;
-      if (lane < 32 && t < a.g.L) {
-        float4* op = (float4*)(a.out + ((size_t)b * a.g.L + t) * 8 + 4 * l4);
-        float4 o = *op;
+      if (valid) {
         o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
         *op = o;
       }
@@ -260,18 +360,22 @@ __global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerAr
   // ---- x_out = fp16(x + res) for valid columns (rows >= L stay zero: they are other tiles' padding)
   if (a.has_res) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (t0 + nt * 32 + ln < a.g.L) {
-        half8 o0, o1;
+    for (int mb = 0; mb < MB; ++mb) {
+      const int blk = wave * MB + mb;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          o0[r] = (_Float16)acc2[nt][r];
-          o1[r] = (_Float16)acc2[nt][8 + r];
+      for (int nt = 0; nt < NT; ++nt) {
+        if (t0 + nt * 32 + ln < a.g.L) {
+          half8 o0, o1;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            o0[r] = (_Float16)acc2[mb][nt][r];
+            o1[r] = (_Float16)acc2[mb][nt][8 + r];
+          }
+          const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + ln;
+          half8* xp = (half8*)(a.x_out + row * 64 + (blk & 1) * 32 + lh * 16);
+          xp[0] = o0;
+          xp[1] = o1;
         }
-        const size_t row = (size_t)my_cc * R + r0 + nt * 32 + ln;
-        half8* xp = (half8*)(a.x_out + row * 64 + my_off);
-        xp[0] = o0;
-        xp[1] = o1;
       }
     }
   }
@@ -279,16 +383,16 @@ __global__ void __launch_bounds__((C / 32) * 64) wn_layer_kernel(const WnLayerAr
 
 template <int C>
 static hipError_t launch_wn_t(const WnLayerArgs& a, hipStream_t s) {
-  constexpr int BN = WnCfg<C>::BN;
+  constexpr int BN = WnCfg<C>::BN, NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + BN * 2 * C;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((wn_layer_kernel<C, BN>), dim3(a.n_tiles), dim3((C / 32) * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN>), dim3(a.n_tiles), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
 }
 
@@ -298,6 +402,15 @@ int wn_block_n(int C) {
     case 128: return WnCfg<128>::BN;
     case 256: return WnCfg<256>::BN;
     case 512: return WnCfg<512>::BN;
+  }
+  return 0;
+}
+int wn_waves(int C) {
+  switch (C) {
+    case 64: return WnCfg<64>::NW;
+    case 128: return WnCfg<128>::NW;
+    case 256: return WnCfg<256>::NW;
+    case 512: return WnCfg<512>::NW;
   }
   return 0;
 }
@@ -313,70 +426,113 @@ hipError_t launch_wn_layer(const WnLayerArgs& a, int C, hipStream_t s) {
 }
 
 // =============================================================================================
-// Upsample: ConvTranspose1d(M, M, 1024, stride 256) written straight into the squeezed planes.
-// out sample tau = 256 q + 8 t' + g gets taps j = 0..3 from frame q - j with kernel index 8t'+g+256j.
-// One workgroup: one t' (phase inside a frame), NF consecutive frames q, all M*8 squeezed channels
-// (one thread per channel; a wave = one 64-channel plane chunk => 128-byte coalesced stores).
+// Upsample: ConvTranspose1d(M, M, 1024, stride 256) (model.py:145-150) written straight into the squeezed
+// conditioning planes (model.py:230-232), as an MFMA GEMM per frame phase t' (= group-timestep inside a frame):
+//   S[ch = o*8+g][frame q] = bias[o] + sum_{j<4, i<M} W[i][o][8t'+g+256j] * mel[i][q-j]
+// i.e. [NS x 4M] . [4M x frames].  One workgroup: one t', 128 consecutive frames of one utterance, all NS
+// channels; 5 waves, wave w owns the 64-channel plane chunks w, w+5, ...  The mel window is transposed once
+// into LDS as fp16 [frame][i] (row stride M+8 halfs => conflict-free ds_read_b128 B fragments); weights come
+// pre-packed in A-fragment order straight from L2.  Output lanes hold 16 consecutive storage positions of one
+// row => two 16-byte stores (spect planes use the same position-major channel order as x, wg_common.h).
 // =============================================================================================
-constexpr int UP_NF = 16;
+constexpr int UP_FRAMES = 128;
+constexpr int UP_WAVES = 5;
 
-__global__ void __launch_bounds__(640) upsample_kernel(const UpsampleArgs a) {
+__global__ void __launch_bounds__(UP_WAVES * 64) upsample_kernel(const UpsampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = a.M;
-  const int ch = threadIdx.x;            // o*8 + g
-  const int tp = blockIdx.x;             // t' in [0, 32)
-  const int q0 = blockIdx.y * UP_NF;
+  const int RS = (M + 8) * 2;                 // melT row stride in bytes
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 31, lh = lane >> 5;
+  const int tp = blockIdx.x;                  // t'
+  const int q0 = blockIdx.y * UP_FRAMES;
   const int b = blockIdx.z;
-  __shared__ float smel[80][UP_NF + 4];  // [i][frame q0-3 .. q0+NF-1]
-  for (int idx = threadIdx.x; idx < M * (UP_NF + 3); idx += blockDim.x) {
-    const int i = idx / (UP_NF + 3), f = idx - i * (UP_NF + 3);
+  const int NF = UP_FRAMES + 3;               // frames q0-3 .. q0+127
+  for (int idx = tid; idx < M * NF; idx += UP_WAVES * 64) {
+    const int i = idx / NF, f = idx - i * NF;
     const int q = q0 - 3 + f;
-    smel[i][f] = (q >= 0 && q < a.T) ? load_io(a.mel, ((size_t)b * M + i) * a.T + q, a.io_f16) : 0.0f;
+    const float v = (q >= 0 && q < a.T) ? load_io(a.mel, ((size_t)b * M + i) * a.T + q, a.io_f16) : 0.0f;
+    *(_Float16*)(smem + f * RS + i * 2) = (_Float16)v;
   }
   __syncthreads();
-  float acc[UP_NF];
-  const float bias = a.bias[ch >> 3];
+  const int KS = M / 4;                       // k16 steps (K = 4M)
+  const int KPJ = M / 16;                     // k16 steps per tap
+  const int NSC = M / 8;                      // 64-channel chunks (NS/64)
+  const half8* const wp = (const half8*)a.w;  // [32 t'][NSC][2 mb][KS][64 lanes][8]
+  for (int cs = wave; cs < NSC; cs += UP_WAVES) {
+    f32x16 acc[2][4];
 #pragma unroll
-  for (int f = 0; f < UP_NF; ++f) acc[f] = bias;
-  const int NCH = M * 8;
-  const float* wp = a.w + (size_t)tp * 4 * M * NCH + ch;
-  for (int j = 0; j < 4; ++j) {
-    for (int i = 0; i < M; ++i) {
-      const float w = wp[((size_t)j * M + i) * NCH];
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 v;
 #pragma unroll
-      for (int f = 0; f < UP_NF; ++f) acc[f] = fmaf(w, smel[i][f + 3 - j], acc[f]);
+      for (int r = 0; r < 16; ++r) {
+        const int ch = cs * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        v[r] = a.bias[ch >> 3];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mb][nt] = v;
     }
-  }
-  const int cs = ch >> 6, cw = ch & 63;
+    const half8* pa = wp + ((size_t)(tp * NSC + cs) * 2 * KS) * 64 + lane;
+    for (int k = 0; k < KS; ++k) {
+      const int j = k / KPJ, i0 = (k - j * KPJ) * 16;
+      const half8 a0 = pa[(size_t)k * 64];
+      const half8 a1 = pa[(size_t)(KS + k) * 64];
+      half8 bf[4];
 #pragma unroll
-  for (int f = 0; f < UP_NF; ++f) {
-    const int t = (q0 + f) * 32 + tp;
-    if (t < a.g.L) {
-      const size_t row = (size_t)b * a.g.Lp + a.g.G + t;
-      a.spect[((size_t)cs * a.g.R + row) * 64 + cw] = (_Float16)acc[f];
+      for (int nt = 0; nt < 4; ++nt)
+        bf[nt] = *(const half8*)(smem + (nt * 32 + ln + 3 - j) * RS + (i0 + 8 * lh) * 2);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[nt], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[nt], acc[1][nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int q = q0 + nt * 32 + ln;
+      const int t = q * 32 + tp;
+      if (t < a.g.L) {
+        const size_t row = (size_t)b * a.g.Lp + a.g.G + t;
+        _Float16* dst = a.spect + ((size_t)cs * a.g.R + row) * 64 + lh * 16;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          half8 o0, o1;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            o0[r] = (_Float16)acc[mb][nt][r];
+            o1[r] = (_Float16)acc[mb][nt][8 + r];
+          }
+          *(half8*)(dst + mb * 32) = o0;
+          *(half8*)(dst + mb * 32 + 8) = o1;
+        }
+      }
     }
   }
 }
 
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s) {
-  if (a.M * 8 > 640 || a.M > 80) return hipErrorInvalidValue;
-  dim3 grid(32, (a.n_q + UP_NF - 1) / UP_NF, a.g.B);
-  hipLaunchKernelGGL(upsample_kernel, grid, dim3(a.M * 8), 0, s, a);
+  if (a.M % 16 != 0 || a.M > 80) return hipErrorInvalidValue;
+  dim3 grid(32, (a.n_q + UP_FRAMES - 1) / UP_FRAMES, a.g.B);
+  const int smem = (UP_FRAMES + 3) * (a.M + 8) * 2;
+  hipLaunchKernelGGL(upsample_kernel, grid, dim3(UP_WAVES * 64), smem, s, a);
   return hipGetLastError();
 }
 
 // =============================================================================================
 // Flow step (both directions) + next WN start.  64 rows per workgroup, 256 threads.
 // =============================================================================================
-constexpr int FL_ROWS = 64;
+constexpr int FL_ROWS = 256;   // rows per workgroup = threads per workgroup
 
-__global__ void __launch_bounds__(256) flow_kernel(const FlowArgs a) {
-  __shared__ float s_a0[FL_ROWS][4];
+__global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
+  __shared__ float4 s_a0[FL_ROWS];
   const int L = a.g.L;
   const size_t nrows = (size_t)a.g.B * L;
   const size_t row0 = (size_t)blockIdx.x * FL_ROWS;
   const int tid = threadIdx.x;
 
-  if (tid < FL_ROWS) {
+  {
     const size_t row = row0 + tid;
     if (row < nrows) {
       const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
@@ -386,31 +542,45 @@ __global__ void __launch_bounds__(256) flow_kernel(const FlowArgs a) {
       if (a.direction == 0) {
         // ------------------------------------------------ inverse flow (model.py:246-271)
         if (a.first) {
-          for (int c = 0; c < a.c_next; ++c)
-            zn[c] = a.sigma * load_io(a.z_extra, ((size_t)b * a.c_next + c) * L + t, a.io_f16);   // :243-244
+#pragma unroll
+          for (int c = 0; c < kMaxGroup; ++c)
+            if (c < a.c_next)
+              zn[c] = a.sigma * load_io(a.z_extra, ((size_t)b * a.c_next + c) * L + t, a.io_f16);   // :243-244
         } else {
-          float z[kMaxGroup], o[kMaxGroup], v[kMaxGroup];
+          float z[kMaxGroup], o[kMaxGroup], v[kMaxGroup], y[kMaxGroup];
           const float4* zp = (const float4*)(a.Z + row * 8);
           const float4* op = (const float4*)(a.out + row * 8);
           float4 z0 = zp[0], z1 = zp[1], o0 = op[0], o1 = op[1];
           z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
           o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
           const int h = a.h_in, c = a.c_in;
+          // v = [a0 ; (a1 - b) / exp(s)]  with b = o[0:h], s = o[h:2h]                               :253-255
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < h) {
-              v[j] = z[j];
-              v[h + j] = (z[h + j] - o[j]) / expf(o[h + j]);                                       // :253-255
-            }
+          for (int j = 0; j < kMaxGroup; ++j) {
+            float num = z[j], den = 1.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j >= h && j - h == q) { num = z[j] - o[q]; den = expf(o[j]); }
+            v[j] = (j < c) ? num / den : 0.0f;
+          }
+#pragma unroll
+          for (int r = 0; r < kMaxGroup; ++r) {                                                     // :258 / :59
+            float s = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < kMaxGroup; ++cc)
+              if (r < c && cc < c) s = fmaf(a.winv[r * c + cc], v[cc], s);
+            y[r] = s;
           }
           const int ne = a.n_extra;
-          for (int r = 0; r < c; ++r) {                                                            // :258 / :59
-            float s = 0.0f;
-            for (int cc = 0; cc < c; ++cc) s = fmaf(a.winv[r * c + cc], v[cc], s);
-            zn[ne + r] = s;
+#pragma unroll
+          for (int e = 0; e < kMaxGroup; ++e) {                                                     // :260-271
+            float val = 0.0f;
+            if (e < ne) val = a.sigma * load_io(a.z_extra, ((size_t)b * ne + e) * L + t, a.io_f16);
+#pragma unroll
+            for (int r = 0; r < kMaxGroup; ++r)
+              if (e >= ne && e - ne == r) val = y[r];
+            zn[e] = val;
           }
-          for (int e = 0; e < ne; ++e)
-            zn[e] = a.sigma * load_io(a.z_extra, ((size_t)b * ne + e) * L + t, a.io_f16);          // :260-271
         }
         if (a.last) {                                                                              // :273
           if (a.io_f16) {
@@ -440,21 +610,37 @@ __global__ void __launch_bounds__(256) flow_kernel(const FlowArgs a) {
           o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
           const int h = a.h_in;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < h) {
-              z[h + j] = expf(o[h + j]) * z[h + j] + o[j];                                         // :213-215
-              a.log_s_out[((size_t)b * h + j) * L + t] = o[h + j];                                 // :216
-            }
+          for (int j = 0; j < kMaxGroup; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j >= h && j - h == q && q < h) {
+                z[j] = expf(o[j]) * z[j] + o[q];                                                   // :213-215
+                a.log_s_out[((size_t)b * h + q) * L + t] = o[j];                                   // :216
+              }
           }
         }
         const int c_in = a.first ? 8 : a.c_in;
         const int np = a.last ? c_in : a.n_peel;                                                   // :201-203, :220
-        for (int e = 0; e < np; ++e) a.z_out[((size_t)b * 8 + a.z_out_ch0 + e) * L + t] = z[e];
+#pragma unroll
+        for (int e = 0; e < kMaxGroup; ++e)
+          if (e < np) a.z_out[((size_t)b * 8 + a.z_out_ch0 + e) * L + t] = z[e];
         if (!a.last) {
           const int c = a.c_next;                                                                  // = c_in - np
-          for (int r = 0; r < c; ++r) {                                                            // :64 W z
+          float zs[kMaxGroup];                                                                     // z[np:]
+#pragma unroll
+          for (int e = 0; e < kMaxGroup; ++e) {
+            float val = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kMaxGroup; ++q)
+              if (q - np == e) val = z[q];
+            zs[e] = val;
+          }
+#pragma unroll
+          for (int r = 0; r < kMaxGroup; ++r) {                                                    // :64  W z
             float s = 0.0f;
-            for (int cc = 0; cc < c; ++cc) s = fmaf(a.winv[r * c + cc], z[np + cc], s);
+#pragma unroll
+            for (int cc = 0; cc < kMaxGroup; ++cc)
+              if (r < c && cc < c) s = fmaf(a.winv[r * c + cc], zs[cc], s);
             zn[r] = s;
           }
         }
@@ -466,8 +652,7 @@ __global__ void __launch_bounds__(256) flow_kernel(const FlowArgs a) {
         float4* op = (float4*)(a.out + row * 8);
         op[0] = make_float4(a.out_init[0], a.out_init[1], a.out_init[2], a.out_init[3]);
         op[1] = make_float4(a.out_init[4], a.out_init[5], a.out_init[6], a.out_init[7]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s_a0[tid][j] = zn[j];
+        s_a0[tid] = make_float4(zn[0], zn[1], zn[2], zn[3]);
       }
     }
   }
@@ -475,33 +660,40 @@ __global__ void __launch_bounds__(256) flow_kernel(const FlowArgs a) {
   __syncthreads();
 
   // ---- WN.start of the next flow (model.py:117): x[P] = sum_j Wst[P][j] a0[j] + b[P], fp16, position-major.
-  // piece = (chunk cc, row, 8-position group): 16 contiguous bytes; consecutive threads -> consecutive bytes.
+  // piece = (chunk cc, row, 8-position group g8) = 16 contiguous bytes; idx = cc*2048 + row*8 + g8, so
+  // consecutive threads write consecutive bytes and a thread's g8 is fixed: its 8x4 weights sit in registers.
   const int C = a.C, h = a.h_next;
-  const int pieces = (C / 64) * FL_ROWS * 8;
-  for (int idx = tid; idx < pieces; idx += 256) {
-    const int cc = idx / (FL_ROWS * 8);
-    const int rem = idx - cc * (FL_ROWS * 8);
-    const int rl = rem >> 3, g8 = rem & 7;
-    const size_t row = row0 + rl;
-    if (row >= nrows) continue;
-    const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+  const int g8 = tid & 7;
+  for (int cc = 0; cc < C / 64; ++cc) {
     const int P0 = cc * 64 + g8 * 8;
-    half8 o;
+    float w[8][4], bs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float s = a.bstart[P0 + e];
-      for (int j = 0; j < h; ++j) s = fmaf(a.wstart[(P0 + e) * h + j], s_a0[rl][j], s);
-      o[e] = (_Float16)s;
+      bs[e] = a.bstart[P0 + e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[e][j] = (j < h) ? a.wstart[(P0 + e) * h + j] : 0.0f;
     }
-    const size_t prow = (size_t)b * a.g.Lp + a.g.G + t;
-    *(half8*)(a.x + ((size_t)cc * a.g.R + prow) * 64 + g8 * 8) = o;
+#pragma unroll
+    for (int it = 0; it < FL_ROWS * 8 / FL_ROWS; ++it) {
+      const int rl = it * (FL_ROWS / 8) + (tid >> 3);
+      const size_t row = row0 + rl;
+      if (row >= nrows) continue;
+      const float4 a0 = s_a0[rl];
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = (_Float16)fmaf(w[e][3], a0.w, fmaf(w[e][2], a0.z, fmaf(w[e][1], a0.y, fmaf(w[e][0], a0.x, bs[e]))));
+      const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+      const size_t prow = (size_t)b * a.g.Lp + a.g.G + t;
+      *(half8*)(a.x + ((size_t)cc * a.g.R + prow) * 64 + g8 * 8) = o;
+    }
   }
 }
 
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s) {
   const size_t nrows = (size_t)a.g.B * a.g.L;
   const unsigned grid = (unsigned)((nrows + FL_ROWS - 1) / FL_ROWS);
-  hipLaunchKernelGGL(flow_kernel, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(flow_kernel, dim3(grid), dim3(FL_ROWS), 0, s, a);
   return hipGetLastError();
 }
 

@@ -44,10 +44,10 @@ struct RowGeom {
 struct WnLayerArgs {
   const _Float16* x_in;     // [C/64][R][64] position-major
   _Float16* x_out;          // same layout (ping-pong), unused when !has_res
-  const _Float16* spect;    // [NS/64][R][64] natural channel order
-  const _Float16* wA1;      // packed GEMM1 A fragments  [nK][NW][2][4][64][8]
+  const _Float16* spect;    // [NS/64][R][64] position-major
+  const _Float16* wA1;      // packed GEMM1 A fragments  [2nK half-steps][NW][MT][2][64][8]
   const float* bias1;       // [2C]  b_in + b_cond slice
-  const _Float16* wA2;      // packed GEMM2 A fragments  [NW][C/16][64][8]
+  const _Float16* wA2;      // packed GEMM2 A fragments  [NW][MB][C/16][64][8]
   const float* bias2;       // [C]   b_res
   const _Float16* wEs;      // packed folded end x skip  [C/32][64][8]  (rows 0-7 hi, 8-15 lo)
   float* out;               // [B*L][8] fp32, accumulated across layers
@@ -61,7 +61,7 @@ struct WnLayerArgs {
 
 struct UpsampleArgs {
   const void* mel;          // [B][M][T] io dtype
-  const float* w;           // packed [32][4][M][M*8]  (t', tap j, in-ch i, out ch o*8+g)
+  const _Float16* w;        // packed A fragments [32 t'][NS/64][2][M/4][64][8]
   const float* bias;        // [M]
   _Float16* spect;          // [NS/64][R][64]
   RowGeom g;
@@ -108,5 +108,6 @@ hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
 hipError_t launch_wn_layer(const WnLayerArgs& a, int C, hipStream_t s);
 int wn_block_n(int C);   // BN used for channel count C
+int wn_waves(int C);     // waves per workgroup for channel count C
 
 }  // namespace wg
