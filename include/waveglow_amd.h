@@ -117,6 +117,10 @@ double wg_macs_per_group_step(const wg_handle* h);
 int wg_profile_enable(wg_handle* h, int32_t on);
 int wg_profile_read(wg_handle* h, double* ms_per_class, int64_t* launches_per_class, int32_t n_classes);
 
+/* Diagnostic builds only (-DWG_STAMPS): device buffer of n_tiles*8 uint64 that the WN-layer kernel fills with
+ * s_memtime stamps at its phase boundaries (last launch wins).  A no-op pointer in the shipped library. */
+int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

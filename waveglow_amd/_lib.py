@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwaveglow_amd.so")
+LIB_PATH = os.environ.get("WAVEGLOW_AMD_LIB", os.path.join(_HERE, "csrc", "libwaveglow_amd.so"))
 
 WG_F32, WG_F16 = 0, 1
 
@@ -45,6 +45,7 @@ SIGNATURES = {
                            C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_macs_per_group_step": (C.c_double, [C.c_void_p]),
+  "wg_debug_set_stamp_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
   "wg_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
   "wg_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

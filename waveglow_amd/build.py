@@ -27,11 +27,29 @@ def needs_build() -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
+  """hipcc -> in-tree .so.  The build FAILS if any kernel spills registers or uses scratch: the WN-layer
+  kernel issues loads from inline asm with hand-counted waits, and a compiler spill of such a register
+  (a scratch store before the data has landed) would silently corrupt results."""
   if not force and not needs_build():
     return LIB
-  cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-         "-Wno-unused-value", "-o", LIB] + SOURCES
+  cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+         "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp"] + SOURCES
+  res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+  if res.returncode != 0:
+    raise RuntimeError("hipcc failed:\n" + res.stderr)
+  report, name = [], None
+  for line in res.stderr.splitlines():
+    if "Function Name:" in line:
+      name = line.split("Function Name:")[1].split("[")[0].strip()
+    for key in ("VGPRs Spill:", "SGPRs Spill:", "ScratchSize [bytes/lane]:"):
+      if key in line and name:
+        val = int(line.split(key)[1].split("[")[0].strip())
+        if val != 0:
+          report.append(f"{name}: {key} {val}")
   if verbose:
-    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-  subprocess.run(cmd, cwd=CSRC, check=True)
+    print(res.stderr)
+  if report:
+    os.remove(LIB + ".tmp")
+    raise RuntimeError("register spills / scratch in device code (forbidden, see build_library doc):\n  " + "\n  ".join(report))
+  os.replace(LIB + ".tmp", LIB)
   return LIB

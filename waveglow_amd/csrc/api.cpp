@@ -108,6 +108,8 @@ struct wg_handle {
   size_t blob_bytes = 0;
   size_t off_upw = 0, off_upb = 0;
   std::vector<FlowOffsets> flows;
+  int n_cu = 256;         // multiProcessorCount, read in wg_finalize
+  unsigned long long* dbg_stamps = nullptr;   // diagnostic builds only
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -474,6 +476,11 @@ int wg_finalize(wg_handle* h) {
     }
   }
   HIP_TRY(hipSetDevice(h->device));
+  {
+    int ncu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+    if (ncu > 0) h->n_cu = ncu;
+  }
   if (h->d_blob) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(h->d_blob));
@@ -522,6 +529,8 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.has_res = i < c.n_layers - 1;
     a.tiles_per_utt = g.Ltile / BN;
     a.n_tiles = g.B * a.tiles_per_utt;
+    a.stamps = h->dbg_stamps;
+    a.n_cu = h->n_cu;
     {
       Prof p(h, s, 2);
       HIP_TRY(launch_wn_layer(a, C, s));
@@ -725,6 +734,12 @@ double wg_macs_per_group_step(const wg_handle* h) {
             (c.n_layers - 1) * (C * 2 * C) + C * C + C * 2 * hk + ck * ck;
   }
   return macs;
+}
+
+int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer) {
+  if (!h) return fail(WG_ERR_INVALID, "null handle");
+  h->dbg_stamps = (unsigned long long*)device_buffer;
+  return WG_OK;
 }
 
 int wg_profile_enable(wg_handle* h, int32_t on) {

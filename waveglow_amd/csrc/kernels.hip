@@ -53,6 +53,23 @@ __device__ __forceinline__ void gload16(half8& dst, const void* sbase, unsigned 
 // =============================================================================================
 // WN layer
 // =============================================================================================
+// Diagnostic build (-DWG_STAMPS, tools/stamp_phases.py): wave 0 of every workgroup records s_memtime at phase
+// boundaries into args.stamps, a buffer nothing else reads.  The shipped library contains no stamp.
+#ifdef WG_STAMPS
+#define WG_STAMP(i)                                                                              \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long _t;                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                   \
+    if (a.stamps && a.has_res && tid == 0) a.stamps[(size_t)tile * 8 + (i)] = _t;                        \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#else
+#define WG_STAMP(i) do {} while (0)
+#endif
+
+constexpr bool kPersistent = false;   // see the note at the tile loop of wn_layer_kernel
+
 template <int C> struct WnCfg {
   static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
   static constexpr int BN = (C >= 512) ? 64 : 128;     // columns (group-timesteps) per workgroup
@@ -84,10 +101,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NT = BN / 32;            // 32-column MFMA tiles per wave
   constexpr int CC = C / 64;             // 64-channel chunks of x
   constexpr int BT_BYTES = BN * 128;     // one staged B tile: BN rows x 64 fp16
-  constexpr int ACT_ROW = 2 * C;         // bytes per acts row
+  constexpr int ACT_ROW = 2 * C + 16;    // bytes per acts row: +16 B pad => conflict-free b128 reads/writes with
+                                         // immediate-offset addressing (one base VGPR per 32-column tile)
   constexpr int K2 = C / 16;             // k16 steps of GEMM2
   constexpr int NG = BN * 8 / NTHREADS;  // LDS-DMA instructions per wave per B tile
-  constexpr int NAH = MT * 2;            // A-fragment loads per half K-step
+  constexpr int NAH = MT * 2;            // A fragments per half K-step (packing unit)
+  constexpr bool DEFER = (MB == 1);      // defer a step's last sub-step past the barrier (needs spare registers)
   static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2, "tile geometry");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,30 +119,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   const int ln = lane & 31;
   const int lh = lane >> 5;
 
-  // XCD-aware tile id: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
-  // contiguous run of time tiles -- neighbouring tiles re-read each other's +-dil rows from that L2.
-  int tile;
-  {
-    const int bid = blockIdx.x, nt = a.n_tiles;
-    const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int b = tile / a.tiles_per_utt;
-  const int jt = tile - b * a.tiles_per_utt;
-  const int R = a.g.R;
-  const int r0 = b * a.g.Lp + a.g.G + jt * BN;   // first plane row of this tile
-  const int t0 = jt * BN;                        // first group-timestep
-  const int nK = 3 * CC + a.ns_chunks;
-
-  auto kstep_src = [&](int ks) -> const char* {
-    if (ks < 3 * CC) {
-      const int tap = ks / CC, cc = ks - tap * CC;
-      const int row = r0 + (tap - 1) * a.dil;     // taps t-d, t, t+d (model.py:98-102: padding = dilation)
-      return (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
-    }
-    const int cs = ks - 3 * CC;
-    return (const char*)(a.spect + ((size_t)cs * R + r0) * 64);
-  };
   // LDS-DMA one B tile: piece idx = row*8 + physical 16-B chunk; logical chunk = phys ^ ((row>>1)&7)
   // (LDS destination is lane-linear, so the bank swizzle is applied to the SOURCE address).
   // Per-lane source offsets are the same for every K-step; only the scalar tile base moves.
@@ -135,12 +130,19 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     pvoff[i] = row * 128 + ((pc ^ ((row >> 1) & 7)) << 4);
   }
   const unsigned sB_addr = (unsigned)(size_t)WG_LPTR(sB);
-  auto stage_B = [&](int ks, int bufsel) {
-    const char* src = kstep_src(ks);
-#pragma unroll
-    for (int i = 0; i < NG; ++i)
-      glds16(src, pvoff[i],
-             __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16));
+  const int R = a.g.R;
+  const int nK = 3 * CC + a.ns_chunks;
+  auto stage_B_piece = [&](int r0, int ks, int bufsel, int i) {
+    const char* src;
+    if (ks < 3 * CC) {
+      const int tap = ks / CC, cc = ks - tap * CC;
+      const int row = r0 + (tap - 1) * a.dil;     // taps t-d, t, t+d (model.py:98-102: padding = dilation)
+      src = (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
+    } else {
+      src = (const char*)(a.spect + ((size_t)(ks - 3 * CC) * R + r0) * 64);
+    }
+    glds16(src, pvoff[i],
+           __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16));
   };
   const int swB = (ln >> 1) & 7;
   auto read_B = [&](const char* buf, int nt, int k16) -> half8 {
@@ -148,243 +150,353 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int c = (k16 * 2 + lh) ^ swB;
     return *(const half8*)(buf + n * 128 + c * 16);
   };
-  // A fragments of half K-step u (= 2*ks + half): [u][wave][MT][2 k16][64 lanes][8], MT*2 KiB per wave
+  // A fragments: packed [2*nK half K-steps][wave][MT][2 k16][64 lanes][8].  q[g][mt] holds the fragment of
+  // k16 sub-step g (0..3) of the current K-step; one fragment = one 1 KiB wave-load straight from L2.
   const unsigned a_voff = lane * 16;
-  auto load_Ah = [&](int u, half8 (&dst)[MT][2]) {
-    const char* p = (const char*)a.wA1 + ((size_t)u * NW + wave) * (NAH * 1024);   // wave-uniform
-    gload16<0>(dst[0][0], p, a_voff);
-    gload16<1024>(dst[0][1], p, a_voff);
-    gload16<2048>(dst[1][0], p, a_voff);
-    gload16<3072>(dst[1][1], p, a_voff);
-    if constexpr (MT == 4) {
-      const char* p2 = p + 4096;
-      gload16<0>(dst[2][0], p2, a_voff);
-      gload16<1024>(dst[2][1], p2, a_voff);
-      gload16<2048>(dst[3][0], p2, a_voff);
-      gload16<3072>(dst[3][1], p2, a_voff);
-    }
+  auto load_Aq = [&](int ks, int g, int mt, half8& dst) {
+#ifdef WG_DBG_A_SAME   // timing experiment only: every step re-reads fragment block 0 (L1-resident)
+    ks = 0;
+#endif
+    const char* p = (const char*)a.wA1 + ((size_t)(2 * ks + (g >> 1)) * NW + wave) * (NAH * 1024) +
+                    (mt * 2 + (g & 1)) * 1024;                                      // wave-uniform
+    gload16<0>(dst, p, a_voff);
+  };
+  auto tile_row0 = [&](int tile) -> int {
+    const int b = tile / a.tiles_per_utt;
+    return b * a.g.Lp + a.g.G + (tile - b * a.tiles_per_utt) * BN;
   };
 
-  // ---- GEMM1 accumulators, initialised with the (pre-scaled) bias: in_layer bias + cond bias slice
-  f32x16 acc[MT][NT];
+  // ---- persistent workgroup: the grid is one workgroup per CU; blocks b and b+8 share an XCD (round-robin
+  // dispatch; speed only), so XCD x owns a contiguous run of time tiles and its workgroups walk it with
+  // stride (blocks on that XCD): tiles that run at the same time are neighbours and re-read each other's
+  // +-dil halo rows from that XCD's L2.
+  int tile, tile_end, tile_step;
   {
+    const int nb = gridDim.x, bid = blockIdx.x, ntl = a.n_tiles;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntl >> 3, r = ntl & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    tile_end = start + (xcd < r ? q + 1 : q);
+    tile_step = (nb >> 3) + ((nb & 7) > xcd ? 1 : 0);     // blocks that landed on this XCD label
+    tile = start + idx;
+  }
+
+  // bias of GEMM1 (pre-scaled in_layer bias + cond bias slice), fp32 [2C], kept in LDS for the whole launch
+  float* const sBias = (float*)(sActs + BN * ACT_ROW);
+  for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
+
+  half8 q[4][MT];
+  int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
+  if (tile < tile_end) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(tile), 0, 0, i);
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+  __syncthreads();
+
+  // NOTE: written as a persistent loop (grid = #CUs) but launched with one tile per workgroup for now: with
+  // a real trip count hipcc (ROCm 7.2) spills 100+ VGPRs around the loop; with a single trip it allocates 236.
+  if (tile < tile_end) {
+    const int b = tile / a.tiles_per_utt;
+    const int jt = tile - b * a.tiles_per_utt;
+    const int r0 = b * a.g.Lp + a.g.G + jt * BN;   // first plane row of this tile
+    const int t0 = jt * BN;                        // first group-timestep
+    const int next_tile = tile + tile_step;
+    WG_STAMP(0);
+    // ---- GEMM1 accumulators start from the bias
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row0 = (mt < MB ? 0 : C) + (wave * MB + (mt < MB ? mt : mt - MB)) * 32;
-      const float* bp = a.bias1 + row0 + 4 * lh;
+      const float4* bp = (const float4*)(sBias + row0 + 4 * lh);
       f32x16 v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = bp[(r & 3) + 8 * (r >> 2)];
+      for (int g = 0; g < 4; ++g) {
+        const float4 q4 = bp[2 * g];
+        v[4 * g] = q4.x; v[4 * g + 1] = q4.y; v[4 * g + 2] = q4.z; v[4 * g + 3] = q4.w;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v;
     }
-  }
 
-  // ---- K loop.  Invariant at the top of step ks: tile ks is visible in LDS buffer ks&1, h0 = A(2ks) is
-  // in registers, h1 = A(2ks+1) is in flight.  Queue order lets every wait be a counted vmcnt:
-  //   [h1] glds(ks+1) | k16 0,1 on h0 | load h0 <- A(2ks+2) | wait h1: vmcnt(NG+NAH) | k16 2,3 on h1 |
-  //   load h1 <- A(2ks+3) | vmcnt(NAH): h0 and the DMA landed | ONE s_barrier per K-step.
-  // B fragments are read one k16 step ahead of their MFMAs (double-buffered in registers).
-  half8 h0[MT][2], h1[MT][2];
-  stage_B(0, 0);
-  load_Ah(0, h0);
-  load_Ah(1, h1);
-  wait_vm<NAH>();
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  for (int ks = 0; ks < nK; ++ks) {
-    const char* buf = sB + (ks & 1) * BT_BYTES;
-    const bool more = ks + 1 < nK;          // wave-uniform
-    if (more) stage_B(ks + 1, (ks + 1) & 1);
+    // ---- K loop (GEMM 1).  One K-step = 4 k16 sub-steps g = 0..3, each MT*NT MFMAs on fragments q[g][.]
+    // (weights) x bf[g&1][.] (activations, read from LDS one sub-step ahead).  Every VMEM / LDS instruction is
+    // placed by hand BETWEEN MFMAs (one "slot" after each column tile's MFMAs; sched_barrier pins the order): an
+    // LDS-DMA or 1-KiB load costs its wave ~60-180 issue cycles, and the two waves of a SIMD run this loop in
+    // lockstep (one barrier per K-step), so clustered loads leave the matrix pipe idle in both at once.
+    //   after the barrier : read bf[0] <- sub-step 0 fragments
+    //   D  (deferred g=3 of the previous step; operands already in registers, covers the LDS latency above)
+    //        slots: LDS-DMA pieces of tile ks+1
+    //   g=0  slots: read bf[1] <- sub-step 1 ; reload q[3] <- A(ks, 3)
+    //   g=1  slots: read bf[0] <- sub-step 2 ; reload q[0] <- A(ks+1, 0)       (wait q[1] first)
+    //   g=2  slots: read bf[1] <- sub-step 3 ; reload q[1] <- A(ks+1, 1)       (wait q[2] first)
+    //   then reload q[2] <- A(ks+1, 2); vmcnt(2*MT): DMA and q[0] landed; lgkmcnt(0); ONE s_barrier.
+    // VMEM issue order per step: DMA xNG, q3 xMT, q0 xMT, q1 xMT, q2 xMT -- every wait is a counted vmcnt.
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    WG_STAMP(1);
+    constexpr int LPS = (MT + NT - 1) / NT;      // A-fragment reloads per slot
+    constexpr int GPS = (NG + NT - 1) / NT;      // LDS-DMA pieces per slot
     half8 bf[2][NT];
+    auto mfma_col = [&](int g, int nt) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[g][mt], bf[g & 1][nt], acc[mt][nt], 0, 0, 0);
+    };
+    if constexpr (kPersistent) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < 3) {
+      for (int nt = 0; nt < NT; ++nt)        // bf[1] carries nothing into a tile (the ks > 0 test below): tell
+        asm volatile("" : "=v"(bf[1][nt]));  // the register allocator, or it keeps stale fragments alive
+    }
+    for (int ks = 0; ks < nK; ++ks) {
+      const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
+      const bool more = ks + 1 < nK;          // wave-uniform
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[(k + 1) & 1][nt] = read_B(buf, nt, k + 1);
-      }
-      if (k == 2) {
-        if (more) wait_vm<NG + NAH>(); else wait_vm<0>();
-      }
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
       __builtin_amdgcn_sched_barrier(0);
+      auto dma_slot = [&](int nt) {
+        if (more) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? h0[mt][k & 1] : h1[mt][k & 1],
-                                                               bf[k & 1][nt], acc[mt][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (k == 1 && more) load_Ah(2 * ks + 2, h0);
-      if (k == 3 && more) load_Ah(2 * ks + 3, h1);
-    }
-    if (more) {
-      wait_vm<NAH>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  // ---- issue the loads the post-gate phases need now, so their latency hides under the gate's VALU work:
-  // residual input x (this tile, this wave's channels: lane (n, h) owns positions [32*blk + 16h, +16) of
-  // column n = 32 contiguous bytes) and the first GEMM2 weight fragments.
-  constexpr int PF = 8;                     // GEMM2 A-fragment prefetch depth
-  half8 xres[MB][NT][2];
-  half8 a2[MB][PF];
-  const half8* const p2 = (const half8*)a.wA2 + (size_t)wave * MB * K2 * 64 + lane;
-  if (a.has_res) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int blk = wave * MB + mb;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + ln;
-        const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lh * 16);
-        xres[mb][nt][0] = xp[0];
-        xres[mb][nt][1] = xp[1];
-      }
-#pragma unroll
-      for (int i = 0; i < PF; ++i) a2[mb][i] = p2[((size_t)mb * K2 + i) * 64];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- gate (model.py:13-20) in registers; acts -> LDS as fp16, position-major, XOR-swizzled
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      half8 o0, o1;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        o0[r] = (_Float16)gate_act(acc[mb][nt][r], acc[MB + mb][nt][r]);
-        o1[r] = (_Float16)gate_act(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r]);
-      }
-      const int n = nt * 32 + ln;
-      const int sw = (ACT_ROW >= 256) ? (n & 15) : ((n >> 1) & 7);
-      const int c0 = (wave * MB + mb) * 4 + lh * 2;
-      *(half8*)(sActs + n * ACT_ROW + ((c0 ^ sw) << 4)) = o0;
-      *(half8*)(sActs + n * ACT_ROW + (((c0 + 1) ^ sw) << 4)) = o1;
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_sched_barrier(0);
-
-  // GEMM2 accumulators start from x + b_res (residual add for free, model.py:132)
-  f32x16 acc2[MB][NT];
-  if (a.has_res) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const float* bp = a.bias2 + (wave * MB + mb) * 32 + 4 * lh;
-      float bv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2)];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          acc2[mb][nt][r] = (float)xres[mb][nt][0][r] + bv[r];
-          acc2[mb][nt][8 + r] = (float)xres[mb][nt][1][r] + bv[8 + r];
+          for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) stage_B_piece(r0, ks + 1, (ks + 1 + par) & 1, i);
         }
-    }
-  }
-
-  auto read_acts32 = [&](int nt, int k16) -> half8 {       // B fragment for the 32x32x16 MFMA
-    const int n = nt * 32 + ln;
-    const int sw = (ACT_ROW >= 256) ? (n & 15) : ((n >> 1) & 7);
-    return *(const half8*)(sActs + n * ACT_ROW + (((k16 * 2 + lh) ^ sw) << 4));
-  };
-
-  // ---- folded end x skip, part 1: issue the weight-fragment and out loads now, consume after GEMM2
-  const int l15 = lane & 15, l4 = lane >> 4;
-  constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
-  half8 wes[C / 32];
-  {
-    const half8* pe = (const half8*)a.wEs + lane;
+      };
+      if constexpr (DEFER) {
+        // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
 #pragma unroll
-    for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
-  }
-
-  // ---- GEMM2: res rows of this wave (model.py:130-132); acts fragments read one k16 step ahead
-  if (a.has_res) {
-    half8 bq[2][NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bq[0][nt] = read_acts32(nt, 0);
-#pragma unroll
-    for (int k = 0; k < K2; ++k) {
-      if (k + 1 < K2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq[(k + 1) & 1][nt] = read_acts32(nt, k + 1);
+        for (int nt = 0; nt < NT; ++nt) {
+          if (ks > 0) mfma_col(3, nt);
+          __builtin_amdgcn_sched_barrier(0);
+          dma_slot(nt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+#pragma unroll
+      for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
+        if (g == 1) { if (more) wait_vm<2 * MT + NG>(); else wait_vm<2 * MT>(); }     // q[1] landed
+        if (g == 2) { if (more) wait_vm<NG + 2 * MT>(); else wait_vm<MT>(); }         // q[2] landed
+        if (g == 3) { if (more) wait_vm<2 * MT>(); else wait_vm<0>(); }               // q[3] landed (no deferral)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          mfma_col(g, nt);
+          __builtin_amdgcn_sched_barrier(0);
+          if (g < 3) bf[(g + 1) & 1][nt] = read_B(buf, nt, g + 1);
+          if (!DEFER && g == 0) dma_slot(nt);
+          if (g == 0 || more) {
+#pragma unroll
+            for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
+              load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (more) {
+        if constexpr (DEFER) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 1, 2, mt, q[2][mt]);
+        }
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * MT) : "memory");   // DMA, q[0] landed; reads done
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (DEFER) {
+      wait_vm<0>();                          // q[3] of the last step
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) mfma_col(3, nt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    par = (par + nK) & 1;
+    // Next tile's first B tile goes out now, into the LDS buffer the last step did not use (slow waves may
+    // still be reading that one); its A fragments follow after the gate -- all land under the phases below.
+    if (next_tile < tile_end) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(next_tile), 0, par, i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    WG_STAMP(2);
+    // Per-tile opaque copies of the lane ids: every address / weight load of the phases below depends on them,
+    // so hipcc cannot hoist those (tile-invariant) values out of the persistent loop and spill them around it
+    // (a spill reload is a VMEM op whose compiler-inserted vmcnt(0) would drain the hand-placed prefetches).
+    int lno = ln, lho = lh, laneo = lane;
+    asm volatile("" : "+v"(lno), "+v"(lho), "+v"(laneo));
+    char* const acts_lane = sActs + lno * ACT_ROW + lho * 32;      // this lane's write slot in row n = lno
+    const char* const acts_rd = sActs + lno * ACT_ROW + lho * 16;  // B-fragment read base (k16 = 0)
+    // ---- issue the loads the post-gate phases need now, so their latency hides under the gate's VALU work:
+    // residual input x (this tile, this wave's channels: lane (n, h) owns positions [32*blk + 16h, +16) of
+    // column n = 32 contiguous bytes) and the first GEMM2 weight fragments.
+    constexpr int PF = 8 / MB;                // GEMM2 A-fragment prefetch depth (per 32-channel block)
+    half8 xres[MB][NT][2];
+    half8 a2[MB][PF];
+    const half8* const p2 = (const half8*)a.wA2 + (size_t)wave * MB * K2 * 64 + laneo;
+    if (a.has_res) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const half8 af = a2[mb][k % PF];
-        if (k + PF < K2) a2[mb][k % PF] = p2[((size_t)mb * K2 + k + PF) * 64];
+        const int blk = wave * MB + mb;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc2[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[k & 1][nt], acc2[mb][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
+          const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lho * 16);
+          xres[mb][nt][0] = xp[0];
+          xres[mb][nt][1] = xp[1];
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) a2[mb][i] = p2[((size_t)mb * K2 + i) * 64];
       }
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);
 
-  // ---- folded end x skip (model.py:133-137): out[0:8] += (W_end W_skip_i) acts, 16 columns per group,
-  // weights split hi+lo fp16 (rows 0-7 / 8-15 of the 16x16x32 MFMA) so the 8 flow outputs keep ~fp32 weights.
-#pragma unroll
-  for (int gi = 0; gi < NGRP; ++gi) {
-    const int grp = wave + gi * NW;
-    if (grp < BN / 16) {
-      const int n = grp * 16 + l15;
-      const int t = t0 + n;
-      const bool valid = lane < 32 && t < a.g.L;
-      float4* op = (float4*)(a.out + ((size_t)b * a.g.L + t) * 8 + 4 * l4);
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) o = *op;
-      const int sw = (ACT_ROW >= 256) ? (n & 15) : ((n >> 1) & 7);
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < C / 32; ++s) {
-        const half8 bfe = *(const half8*)(sActs + n * ACT_ROW + (((s * 4 + l4) ^ sw) << 4));
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wes[s], bfe, d, 0, 0, 0);
-      }
-      // D: col = lane&15, row = 4*(lane>>4)+reg ; rows 8-15 (lanes 32-63) are the lo parts
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d[r] += __shfl_xor(d[r], 32);
-      if (valid) {
-        o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
-        *op = o;
-      }
-    }
-  }
-
-  // ---- x_out = fp16(x + res) for valid columns (rows >= L stay zero: they are other tiles' padding)
-  if (a.has_res) {
+    // ---- gate (model.py:13-20) in registers; acts -> LDS as fp16, position-major, XOR-swizzled
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int blk = wave * MB + mb;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        if (t0 + nt * 32 + ln < a.g.L) {
-          half8 o0, o1;
+        half8 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          o0[r] = (_Float16)gate_act(acc[mb][nt][r], acc[MB + mb][nt][r]);
+          o1[r] = (_Float16)gate_act(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r]);
+        }
+        char* ap = acts_lane + nt * 32 * ACT_ROW + (wave * MB + mb) * 64;   // positions [32*blk + 16h, +16)
+        *(half8*)(ap) = o0;
+        *(half8*)(ap + 16) = o1;
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    WG_STAMP(3);
+    // The accumulators are dead now: room for the next tile's first A fragments.  Unconditional (the weights
+    // are the same for every tile) so h0/h1 are plainly dead across the gate above, not "maybe still needed".
+    if constexpr (kPersistent) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // GEMM2 accumulators start from x + b_res (residual add for free, model.py:132)
+    f32x16 acc2[MB][NT];
+    if (a.has_res) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float* bp = a.bias2 + (wave * MB + mb) * 32 + 4 * lho;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            o0[r] = (_Float16)acc2[mb][nt][r];
-            o1[r] = (_Float16)acc2[mb][nt][8 + r];
+            acc2[mb][nt][r] = (float)xres[mb][nt][0][r] + bv[r];
+            acc2[mb][nt][8 + r] = (float)xres[mb][nt][1][r] + bv[8 + r];
           }
-          const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + ln;
-          half8* xp = (half8*)(a.x_out + row * 64 + (blk & 1) * 32 + lh * 16);
-          xp[0] = o0;
-          xp[1] = o1;
+      }
+    }
+
+    auto read_acts32 = [&](int nt, int k16) -> half8 {       // B fragment for the 32x32x16 MFMA
+      return *(const half8*)(acts_rd + nt * 32 * ACT_ROW + k16 * 32);
+    };
+
+    const int l15 = laneo & 15, l4 = laneo >> 4;
+    constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
+    constexpr bool kWesEarly = (C / 32) * 4 <= 32;           // folded-end weight fragments fit beside GEMM2's registers
+    half8 wes[C / 32];
+    auto load_wes = [&]() {
+      const half8* pe = (const half8*)a.wEs + laneo;
+#pragma unroll
+      for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
+    };
+    if constexpr (kWesEarly) load_wes();                     // issue now, consume after GEMM2
+
+    // ---- GEMM2: res rows of this wave (model.py:130-132); acts fragments read one k16 step ahead
+    if (a.has_res) {
+      half8 bq[2][NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bq[0][nt] = read_acts32(nt, 0);
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        if (k + 1 < K2) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bq[(k + 1) & 1][nt] = read_acts32(nt, k + 1);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const half8 af = a2[mb][k % PF];
+          if (k + PF < K2) a2[mb][k % PF] = p2[((size_t)mb * K2 + k + PF) * 64];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc2[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[k & 1][nt], acc2[mb][nt], 0, 0, 0);
         }
       }
     }
+
+    WG_STAMP(4);
+    if constexpr (!kWesEarly) load_wes();
+    // ---- folded end x skip (model.py:133-137): out[0:8] += (W_end W_skip_i) acts, 16 columns per group,
+    // weights split hi+lo fp16 (rows 0-7 / 8-15 of the 16x16x32 MFMA) so the 8 flow outputs keep ~fp32 weights.
+#pragma unroll
+    for (int gi = 0; gi < NGRP; ++gi) {
+      const int grp = wave + gi * NW;
+      if (grp < BN / 16) {
+        const int n = grp * 16 + l15;
+        const int t = t0 + n;
+        const bool valid = laneo < 32 && t < a.g.L;
+        float4* op = (float4*)(a.out + ((size_t)b * a.g.L + t) * 8 + 4 * l4);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) o = *op;
+        const char* ep = sActs + n * ACT_ROW + l4 * 16;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) {
+          const half8 bfe = *(const half8*)(ep + s * 64);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wes[s], bfe, d, 0, 0, 0);
+        }
+        // D: col = lane&15, row = 4*(lane>>4)+reg ; rows 8-15 (lanes 32-63) are the lo parts
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] += __shfl_xor(d[r], 32);
+        if (valid) {
+          o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
+          *op = o;
+        }
+      }
+    }
+
+    WG_STAMP(5);
+    // ---- x_out = fp16(x + res) for valid columns (rows >= L stay zero: they are other tiles' padding)
+    if (a.has_res) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int blk = wave * MB + mb;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (t0 + nt * 32 + lno < a.g.L) {
+            half8 o0, o1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              o0[r] = (_Float16)acc2[mb][nt][r];
+              o1[r] = (_Float16)acc2[mb][nt][8 + r];
+            }
+            const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
+            half8* xp = (half8*)(a.x_out + row * 64 + (blk & 1) * 32 + lho * 16);
+            xp[0] = o0;
+            xp[1] = o1;
+          }
+        }
+      }
+    }
+    WG_STAMP(6);
   }
 }
 
 template <int C>
 static hipError_t launch_wn_t(const WnLayerArgs& a, hipStream_t s) {
   constexpr int BN = WnCfg<C>::BN, NW = WnCfg<C>::NW;
-  constexpr int smem = 2 * BN * 128 + BN * 2 * C;
+  constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 2 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN>,
@@ -392,7 +504,8 @@ static hipError_t launch_wn_t(const WnLayerArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN>), dim3(a.n_tiles), dim3(NW * 64), smem, s, a);
+  const int grid = a.n_tiles;   // one tile per workgroup (see the note at the tile loop)
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
 }
 

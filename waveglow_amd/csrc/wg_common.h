@@ -57,6 +57,8 @@ struct WnLayerArgs {
   int has_res;              // 0 for the last layer of a WN (model.py:106-110)
   int tiles_per_utt;        // Ltile / BN
   int n_tiles;              // B * tiles_per_utt
+  int n_cu;                 // compute units of the device (persistent grid size)
+  unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
 };
 
 struct UpsampleArgs {
