@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "waveglow_amd", "csrc")
 lib = os.path.join(ROOT, "gpurun_out", "libwaveglow_amd_stamps.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-extra = [f for f in sys.argv[2:] if f.startswith("-D")]
+extra = [f for f in sys.argv[2:] if f.startswith("-D") and f != "-DNONE"]
 subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
                 "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "api.cpp"], cwd=csrc, check=True)
 os.environ["WAVEGLOW_AMD_LIB"] = lib

@@ -13,6 +13,8 @@
 // through the SOURCE address (LDS destination is lane-linear).
 #include "wg_common.h"
 
+#include <type_traits>
+
 namespace wg {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -132,20 +134,25 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   const unsigned sB_addr = (unsigned)(size_t)WG_LPTR(sB);
   const int R = a.g.R;
   const int nK = 3 * CC + a.ns_chunks;
-  auto stage_B_piece = [&](int r0, int ks, int bufsel, int i) {
-    const char* src;
+  auto kstep_src = [&](int r0, int ks) -> const char* {      // scalar: B-tile source of K-step ks
     if (ks < 3 * CC) {
       const int tap = ks / CC, cc = ks - tap * CC;
       const int row = r0 + (tap - 1) * a.dil;     // taps t-d, t, t+d (model.py:98-102: padding = dilation)
-      src = (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
-    } else {
-      src = (const char*)(a.spect + ((size_t)(ks - 3 * CC) * R + r0) * 64);
+      return (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
     }
-    glds16(src, pvoff[i],
+    return (const char*)(a.spect + ((size_t)(ks - 3 * CC) * R + r0) * 64);
+  };
+  auto stage_B_piece = [&](int r0, int ks, int bufsel, int i) {
+#ifndef WG_DBG_NO_DMA
+    glds16(kstep_src(r0, ks), pvoff[i],
            __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16));
+#endif
   };
   const int swB = (ln >> 1) & 7;
   auto read_B = [&](const char* buf, int nt, int k16) -> half8 {
+#ifdef WG_DBG_NO_LDSREAD
+    half8 z; asm volatile("" : "=v"(z)); return z;
+#endif
     const int n = nt * 32 + ln;
     const int c = (k16 * 2 + lh) ^ swB;
     return *(const half8*)(buf + n * 128 + c * 16);
@@ -159,7 +166,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #endif
     const char* p = (const char*)a.wA1 + ((size_t)(2 * ks + (g >> 1)) * NW + wave) * (NAH * 1024) +
                     (mt * 2 + (g & 1)) * 1024;                                      // wave-uniform
+#ifndef WG_DBG_NO_ALOAD
     gload16<0>(dst, p, a_voff);
+#else
+    asm volatile("" : "=v"(dst));
+#endif
   };
   auto tile_row0 = [&](int tile) -> int {
     const int b = tile / a.tiles_per_utt;
@@ -252,57 +263,82 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       for (int nt = 0; nt < NT; ++nt)        // bf[1] carries nothing into a tile (the ks > 0 test below): tell
         asm volatile("" : "=v"(bf[1][nt]));  // the register allocator, or it keeps stale fragments alive
     }
-    for (int ks = 0; ks < nK; ++ks) {
+    // One K-step; MORE = "a next step exists" is a compile-time flag (the last step is peeled) so the body has
+    // no branches (so are the first step's missing deferred MFMAs), and the next tile's DMA source is computed
+    // once per step in scalar registers.
+    auto kstep = [&](auto more_tag, auto first_tag, auto hi_tag, int ks) {
+      constexpr bool more = decltype(more_tag)::value;
+      constexpr bool first = decltype(first_tag)::value;
+      // Stagger: the two waves of a SIMD (w, w + NW/2) run this loop in lockstep; the upper half takes its
+      // VMEM slots half a sub-step later, so one wave's load issue sits beside its partner's MFMAs.
+      constexpr int SH = decltype(hi_tag)::value ? NT / 2 : 0;
       const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
-      const bool more = ks + 1 < nK;          // wave-uniform
+      const char* src_next = nullptr;
+      if constexpr (more) src_next = kstep_src(r0, ks + 1);
+      const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
       __builtin_amdgcn_sched_barrier(0);
       auto dma_slot = [&](int nt) {
-        if (more) {
+        if constexpr (more) {
 #pragma unroll
-          for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) stage_B_piece(r0, ks + 1, (ks + 1 + par) & 1, i);
+          for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i)
+            glds16(src_next, pvoff[i], __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16));
         }
       };
       if constexpr (DEFER) {
         // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          if (ks > 0) mfma_col(3, nt);
+          if constexpr (!first) mfma_col(3, nt);
           __builtin_amdgcn_sched_barrier(0);
-          dma_slot(nt);
+          dma_slot((nt + NT - SH) % NT);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
       for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
-        if (g == 1) { if (more) wait_vm<2 * MT + NG>(); else wait_vm<2 * MT>(); }     // q[1] landed
-        if (g == 2) { if (more) wait_vm<NG + 2 * MT>(); else wait_vm<MT>(); }         // q[2] landed
-        if (g == 3) { if (more) wait_vm<2 * MT>(); else wait_vm<0>(); }               // q[3] landed (no deferral)
+        if (g == 1) wait_vm<more ? 2 * MT + NG : 2 * MT>();      // q[1] landed
+        if (g == 2) wait_vm<more ? NG + 2 * MT : MT>();          // q[2] landed
+        if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           mfma_col(g, nt);
           __builtin_amdgcn_sched_barrier(0);
           if (g < 3) bf[(g + 1) & 1][nt] = read_B(buf, nt, g + 1);
-          if (!DEFER && g == 0) dma_slot(nt);
+          const int snt = (nt + NT - SH) % NT;
+          if (!DEFER && g == 0) dma_slot(snt);
           if (g == 0 || more) {
 #pragma unroll
-            for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
+            for (int mt = snt * LPS; mt < (snt + 1) * LPS && mt < MT; ++mt)
               load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (more) {
+      if constexpr (more) {
         if constexpr (DEFER) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 1, 2, mt, q[2][mt]);
         }
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * MT) : "memory");   // DMA, q[0] landed; reads done
+#ifndef WG_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    auto kloop = [&](auto hi_tag) {
+      kstep(std::true_type{}, std::true_type{}, hi_tag, 0);    // nK >= 13: first, middle and last steps all exist
+#pragma clang loop unroll(disable)
+      for (int ks = 1; ks < nK - 1; ++ks) kstep(std::true_type{}, std::false_type{}, hi_tag, ks);
+      kstep(std::false_type{}, std::false_type{}, hi_tag, nK - 1);
+    };
+#ifdef WG_STAGGER   // experiment: two copies of the loop push hipcc into spilling (26 VGPRs @C=256) -- off
+    if (wave >= NW / 2) kloop(std::true_type{}); else kloop(std::false_type{});
+#else
+    kloop(std::false_type{});
+#endif
     if constexpr (DEFER) {
       wait_vm<0>();                          // q[3] of the last step
 #pragma unroll
