@@ -38,15 +38,33 @@ def gpu_infer(model, mel, z_init, z_early, sigma, dtype=torch.float32):
 
 
 @pytest.mark.parametrize("name", ["c64", "c256", "c512"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_infer_golden(name, dtype):
+def test_infer_golden_fp32(name):
+  """fp32 I/O against the committed output of the reference itself."""
   c = Case(name)
   model = build_model(c.hp, c.sd)
-  out = gpu_infer(model, c.mel, c.z_init, c.z_early, c.sigma, dtype)
+  out = gpu_infer(model, c.mel, c.z_init, c.z_early, c.sigma, torch.float32)
   err = rms(out - c.audio)
-  print(f"{name} {dtype}: rms err {err:.3e} max {float((out - c.audio).abs().max()):.3e} signal rms {rms(c.audio):.3f}")
+  print(f"{name} fp32: rms err {err:.3e} max {float((out - c.audio).abs().max()):.3e} signal rms {rms(c.audio):.3f}")
   assert out.shape == c.audio.shape
   assert torch.isfinite(out).all()
+  assert err <= RMS_TOL
+
+
+@pytest.mark.parametrize("name", ["c64", "c256", "c512"])
+def test_infer_golden_case_fp16_io(name):
+  """fp16 I/O: "identical mel + noise" means the fp16 tensors the kernel actually receives, so the CPU fp32
+  oracle is evaluated on the fp16-rounded inputs of the golden case (the reference's own half path also draws its
+  noise in fp16, model.py:234-237)."""
+  from oracle import torch_oracle as O
+  c = Case(name)
+  mel16, z16 = c.mel.half().float(), c.z_init.half().float()
+  ze16 = {k: v.half().float() for k, v in c.z_early.items()}
+  with torch.no_grad():
+    ref = O.infer_ref(c.sd, mel16, z16, ze16, c.sigma, c.oracle_cfg())
+  model = build_model(c.hp, c.sd)
+  out = gpu_infer(model, c.mel, c.z_init, c.z_early, c.sigma, torch.float16)
+  err = rms(out - ref)
+  print(f"{name} fp16 io: rms err {err:.3e} max {float((out - ref).abs().max()):.3e}")
   assert err <= RMS_TOL
 
 
@@ -82,17 +100,41 @@ def test_infer_c256_vs_oracle_medium():
   mel = synthetic.make_mel(B, T)
   z_init, z_early = synthetic.make_noise(hp, B, 32 * T)
   torch.set_num_threads(16)
-  with torch.no_grad():
-    ref = O.infer_ref(sd, mel, z_init, z_early, 0.6, oracle_cfg_from_hp(hp))
   model = build_model(hp, sd)
   for dtype in (torch.float32, torch.float16):
+    rnd = (lambda t: t.to(dtype).float())
+    with torch.no_grad():
+      ref = O.infer_ref(sd, rnd(mel), rnd(z_init), {k: rnd(v) for k, v in z_early.items()}, 0.6, oracle_cfg_from_hp(hp))
     out = gpu_infer(model, mel, z_init, z_early, 0.6, dtype)
     err = rms(out - ref)
     print(f"c256 B{B} T{T} {dtype}: rms err {err:.3e} (signal {rms(ref):.3f})")
     assert err <= RMS_TOL
 
 
-@pytest.mark.parametrize("name", ["c64", "c256"])
+def test_weights_update_rebuilds_derived_state():
+  """The reference caches W_inverse as a plain attribute and goes stale (model.py:52-58); here every packed layout
+  incl. W^-1 is re-derived when parameters change -- also after .half()."""
+  from oracle import torch_oracle as O
+  hp = HParams(n_channels=64, n_layers=4, n_flows=4, n_early_every=2)
+  sd1, sd2 = synthetic.make_state_dict(hp, seed=21), synthetic.make_state_dict(hp, seed=22)
+  B, T = 1, 6
+  mel = synthetic.make_mel(B, T)
+  z_init, z_early = synthetic.make_noise(hp, B, 32 * T)
+  model = build_model(hp, sd1)
+  cfg = oracle_cfg_from_hp(hp)
+  out1 = gpu_infer(model, mel, z_init, z_early, 0.9)
+  model.load_state_dict(sd2)
+  out2 = gpu_infer(model, mel, z_init, z_early, 0.9)
+  with torch.no_grad():
+    ref1 = O.infer_ref(sd1, mel, z_init, z_early, 0.9, cfg)
+    ref2 = O.infer_ref(sd2, mel, z_init, z_early, 0.9, cfg)
+  assert rms(out1 - ref1) <= RMS_TOL and rms(out2 - ref2) <= RMS_TOL
+  model.half()
+  out3 = gpu_infer(model, mel, z_init, z_early, 0.9, torch.float16)
+  assert rms(out3 - ref2) <= 3e-3     # weights themselves were rounded to fp16 by .half()
+
+
+@pytest.mark.parametrize("name", ["c64", "c256", "c512"])
 def test_forward_golden(name):
   c = Case(name)
   model = build_model(c.hp, c.sd)
@@ -149,3 +191,35 @@ def test_cpu_tensor_is_an_error_not_a_fallback():
   m = WaveGlow(hp)
   with pytest.raises(WgError):
     m.infer(torch.zeros(1, 80, 4))
+
+
+def test_synthesizer_and_cli_end_to_end(tmp_path):
+  """Checkpoint file in the reference's format -> Synthesizer -> wav on disk through ``waveglow-cli synthesize``."""
+  import numpy as np
+  from scipy.io import wavfile
+  from waveglow_amd.checkpoint import CheckpointWaveglow
+  from waveglow_amd.synthesizer import Synthesizer
+  from waveglow_amd import cli
+  hp = HParams(n_channels=64, n_layers=4, n_flows=4, n_early_every=2)
+  m = WaveGlow(hp)
+  m.load_state_dict(synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=5)))
+  ck_path = tmp_path / "10.pt"
+  CheckpointWaveglow.from_instances(m, None, hp, 10).save(ck_path)
+  ck = CheckpointWaveglow.load(ck_path, torch.device("cuda:0"))
+  synth = Synthesizer(ck, device=torch.device("cuda:0"))
+  mel = synthetic.make_mel(1, 12)
+  r1 = synth.infer(mel, sigma=0.7, denoiser_strength=0.0005, seed=3)
+  r2 = synth.infer(mel, sigma=0.7, denoiser_strength=0.0005, seed=3)
+  assert r1.sampling_rate == 22050 and r1.wav.shape == (12 * 256,) and r1.wav_denoised.shape == (12 * 256,)
+  assert np.array_equal(r1.wav, r2.wav)                    # seeded on every call (utils.py:221-229)
+  assert r1.inference_duration_s > 0 and r1.denoising_duration_s > 0
+  assert not np.array_equal(r1.wav, synth.infer(mel, sigma=0.7, seed=4).wav)
+  mels = tmp_path / "mels" / "sub"
+  mels.mkdir(parents=True)
+  np.save(mels / "a.npy", mel[0].numpy())
+  out = tmp_path / "out"
+  rc = cli.main(["synthesize", str(ck_path), str(tmp_path / "mels"), "--sigma", "0.7", "--custom-seed", "3",
+                 "--device", "cuda:0", "-out", str(out)])
+  assert rc == 0
+  rate, data = wavfile.read(out / "sub" / "a.wav")
+  assert rate == 22050 and data.dtype == np.int16 and data.shape == (12 * 256,) and np.abs(data).max() == 32767

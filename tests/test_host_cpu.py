@@ -1,0 +1,128 @@
+"""Host-side (no GPU) checks of the drop-in boundary: names, shapes, formats, error behaviour."""
+import dataclasses
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from waveglow_amd import synthetic
+from waveglow_amd.audio import convert_wav, is_overamp, normalize_wav
+from waveglow_amd.checkpoint import CheckpointWaveglow
+from waveglow_amd.hparams import HParams, overwrite_custom_hparams, split_hparams_string
+from waveglow_amd.model import WaveGlow
+from waveglow_amd.sharding import shard_list, shard_range
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+
+
+@pytest.mark.parametrize("tag", ["default", "c64_f4"])
+def test_state_dict_keys_and_shapes_match_reference(tag):
+  """Fixture = the reference's own state_dict (tests/golden/make_state_dict_keys.py): 686 keys weight-normed,
+  470 after remove_weightnorm for the default hparams."""
+  fx = KEYS[tag]
+  m = WaveGlow(HParams(**fx["hparams"]))
+  got = {k: list(v.shape) for k, v in m.state_dict().items()}
+  assert got == fx["weight_normed"]
+  assert sum(p.numel() for p in m.parameters()) == fx["n_params_weight_normed"]
+  m = WaveGlow.remove_weightnorm(m)
+  got = {k: list(v.shape) for k, v in m.state_dict().items()}
+  assert got == fx["weight_norm_removed"]
+  if tag == "default":
+    assert len(fx["weight_normed"]) == 686 and len(fx["weight_norm_removed"]) == 470
+
+
+def test_dense_state_names_are_the_470_key_form():
+  fx = KEYS["c64_f4"]
+  m = WaveGlow(HParams(**fx["hparams"]))
+  with torch.no_grad():
+    dense = m.dense_state()
+  assert {k: list(v.shape) for k, v in dense.items()} == fx["weight_norm_removed"]
+
+
+def test_weightnorm_fold_matches_dense_weights():
+  hp = HParams(n_channels=64, n_flows=4, n_early_every=2, n_layers=3)
+  sd = synthetic.make_state_dict(hp, seed=2)
+  m = WaveGlow(hp)
+  m.load_state_dict(synthetic.to_weightnorm_form(sd))
+  with torch.no_grad():
+    dense = m.dense_state()
+  for k, v in sd.items():
+    assert torch.allclose(dense[k], v, rtol=1e-5, atol=1e-7), k
+
+
+def test_legacy_weight_g_weight_v_checkpoint_keys_load():
+  """NVIDIA-era checkpoints store weight norm as ``weight_g`` / ``weight_v``."""
+  hp = HParams(n_channels=64, n_flows=4, n_early_every=2, n_layers=3)
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=3))
+  legacy = {}
+  for k, v in sd.items():
+    k = k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v")
+    legacy[k] = v
+  m = WaveGlow(hp)
+  m.load_state_dict(legacy)
+  assert torch.equal(m.WN[1].in_layers[2].parametrizations.weight.original1, sd["WN.1.in_layers.2.parametrizations.weight.original1"])
+
+
+def test_custom_hparams_follow_reference_semantics():
+  hp = HParams()
+  assert split_hparams_string("n_channels=512,sigma=0.6") == {"n_channels": "512", "sigma": "0.6"}
+  hp2 = overwrite_custom_hparams(hp, {"n_channels": "512", "sigma": "0.6"})
+  assert hp2.n_channels == 512 and isinstance(hp2.n_channels, int) and hp2.sigma == 0.6
+  assert overwrite_custom_hparams(hp, None) is hp
+  with pytest.raises(Exception):
+    overwrite_custom_hparams(hp, {"no_such_param": "1"})     # utils.py:53-54: bare Exception
+  assert overwrite_custom_hparams(hp, {"window": ""}).window is None   # utils.py:76-82
+  # field names are the checkpoint format
+  for name in ("segment_length", "n_mel_channels", "n_flows", "n_group", "n_early_every", "n_early_size", "n_layers",
+               "n_channels", "kernel_size", "sampling_rate", "filter_length", "hop_length", "learning_rate", "sigma"):
+    assert name in {f.name for f in dataclasses.fields(HParams)}
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+  hp = HParams(n_channels=64, n_flows=4, n_early_every=2, n_layers=3)
+  m = WaveGlow(hp)
+  opt = torch.optim.Adam(m.parameters(), lr=hp.learning_rate)
+  ck = CheckpointWaveglow.from_instances(m, opt, hp, iteration=7)
+  path = tmp_path / "7.pt"
+  ck.save(path)
+  raw = torch.load(path, weights_only=True)
+  assert set(raw) == {"state_dict", "optimizer", "learning_rate", "iteration", "hparams"}   # checkpoint.py:13-20
+  ck2 = CheckpointWaveglow.load(path, torch.device("cpu"))
+  assert ck2.iteration == 7 and ck2.get_hparams() == hp
+  raw["hparams"]["some_future_field"] = 1
+  assert CheckpointWaveglow(**raw).get_hparams() == hp     # unknown keys dropped (checkpoint.py:22-28)
+  m2 = WaveGlow(ck2.get_hparams())
+  m2.load_state_dict(ck2.state_dict)
+
+
+def test_shard_ranges_partition_the_list():
+  for n in (0, 1, 7, 8, 9, 256):
+    for w in (1, 2, 3, 8):
+      spans = [shard_range(n, r, w) for r in range(w)]
+      assert spans[0][0] == 0 and spans[-1][1] == n
+      assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+      sizes = [e - s for s, e in spans]
+      assert max(sizes) - min(sizes) <= 1
+  assert shard_list(list("abcde"), 1, 2) == ["d", "e"]
+
+
+def test_wav_helpers():
+  x = np.array([0.5, -0.25, 0.1], dtype=np.float32)
+  n = normalize_wav(x)
+  assert np.max(np.abs(n)) == 1.0 and not is_overamp(n)
+  assert is_overamp(np.array([1.5], dtype=np.float32))
+  i16 = convert_wav(n, np.int16)
+  assert i16.dtype == np.int16 and i16[0] == 32767 and i16[1] == -16384
+  assert np.array_equal(normalize_wav(np.zeros(4, dtype=np.float32)), np.zeros(4, dtype=np.float32))
+
+
+def test_synthetic_inputs_are_deterministic():
+  hp = HParams()
+  a, b = synthetic.make_mel(2, 5), synthetic.make_mel(2, 5)
+  assert torch.equal(a, b) and a.min() >= -11.5 and a.max() <= 2.0
+  z, ze = synthetic.make_noise(hp, 2, 160)
+  assert z.shape == (2, 4, 160) and sorted(ze) == [4, 8] and ze[8].shape == (2, 2, 160)
+  assert synthetic.flow_channels(hp) == [8, 8, 8, 8, 6, 6, 6, 6, 4, 4, 4, 4]

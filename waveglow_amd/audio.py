@@ -1,0 +1,51 @@
+"""The few wav helpers the synthesize path needs (src/waveglow/audio_utils.py:26-32, :36-64, :67-95, :132-138)."""
+from __future__ import annotations
+
+import numpy as np
+from scipy.io.wavfile import write
+
+
+def _min_max(dtype):
+  if dtype == np.int16:
+    return -32768, 32767
+  if dtype == np.int32:
+    return -2147483648, 2147483647
+  if dtype in (np.float32, np.float64):
+    return -1.0, 1.0
+  raise AssertionError(dtype)
+
+
+def is_overamp(wav: np.ndarray) -> bool:
+  lo, hi = _min_max(wav.dtype)
+  return bool(np.min(wav) < lo or np.max(wav) > hi)
+
+
+def normalize_wav(wav: np.ndarray) -> np.ndarray:
+  """Scale so that max |x| hits the dtype's maximum (audio_utils.py:67-95)."""
+  lo, hi = _min_max(wav.dtype)
+  if wav.dtype in (np.int16, np.int32) and np.min(wav) == lo:
+    return wav
+  max_val = np.max(np.abs(wav))
+  if max_val != hi and max_val != 0:
+    orig = wav.dtype
+    wf = wav.astype(np.float32) * hi / max_val
+    if orig in (np.int16, np.int32):
+      wf = np.round(wf, 0)
+    wav = wf.astype(orig)
+  return wav
+
+
+def convert_wav(wav: np.ndarray, to_dtype) -> np.ndarray:
+  """float [-1,1] -> integer PCM with rounding (audio_utils.py:36-64)."""
+  if wav.dtype != to_dtype:
+    _, hi = _min_max(to_dtype)
+    _, cur_hi = _min_max(wav.dtype)
+    wav = wav / cur_hi * hi
+    if to_dtype in (np.int16, np.int32):
+      wav = np.round(wav, 0)
+    wav = wav.astype(to_dtype)
+  return wav
+
+
+def float_to_wav(wav: np.ndarray, path, dtype=np.int16, sample_rate: int = 22050) -> None:
+  write(filename=path, rate=sample_rate, data=convert_wav(wav, dtype))

@@ -1,0 +1,85 @@
+"""``waveglow-cli synthesize`` with the reference's flags and file conventions
+(src/waveglow_cli/inference_v2.py:53-130, helper.py:8-22, defaults.py:9-10), plus real batching (the reference's
+commented-out ``--batch-size``, inference_v2.py:64) and per-rank sharding of the file list under torch.distributed.run.
+
+  python -m waveglow_amd.cli synthesize CHECKPOINT FOLDER [--sigma S] [--denoiser-strength D] [--device cuda:0]
+         [--custom-hparams a=1,b=2] [--custom-seed N] [-out DIR] [-o]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+from logging import getLogger
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .audio import float_to_wav, normalize_wav
+from .checkpoint import CheckpointWaveglow
+from .hparams import split_hparams_string
+from .sharding import shard_list
+from .synthesizer import Synthesizer
+
+
+def _unit_float(v: str) -> float:
+  f = float(v)
+  if not 0 <= f <= 1:
+    raise argparse.ArgumentTypeError("Value needs to be in interval [0, 1]!")
+  return f
+
+
+def build_parser() -> argparse.ArgumentParser:
+  p = argparse.ArgumentParser(prog="waveglow-cli")
+  sub = p.add_subparsers(dest="command", required=True)
+  s = sub.add_parser("synthesize", description="Synthesize mel-spectrograms to audio files (.wav).")
+  s.add_argument("checkpoint", type=Path, metavar="CHECKPOINT")
+  s.add_argument("folder", type=Path, metavar="FOLDER")
+  s.add_argument("--sigma", type=_unit_float, default=1.0)
+  s.add_argument("--denoiser-strength", type=_unit_float, default=0.0005)
+  s.add_argument("--device", type=str, default="cuda:0")
+  s.add_argument("--custom-hparams", type=str, default=None)
+  s.add_argument("--custom-seed", type=int, default=None)
+  s.add_argument("-out", "--output-directory", type=Path, default=None)
+  s.add_argument("-o", "--overwrite", action="store_true")
+  return p
+
+
+def synthesize(ns) -> bool:
+  logger = getLogger(__name__)
+  rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+  device = torch.device(ns.device if world == 1 else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+  out_dir = ns.output_directory or ns.folder
+  if out_dir.is_file():
+    logger.error("Output directory is a file!")
+    return False
+  seed = ns.custom_seed if ns.custom_seed is not None else random.randint(1, 9999)
+  try:
+    ckpt = CheckpointWaveglow.load(ns.checkpoint, device)
+  except Exception:
+    logger.error("Checkpoint couldn't be loaded!")
+    return False
+  mel_files = sorted(p for p in ns.folder.rglob("*") if p.is_file() and p.suffix.lower() == ".npy")
+  mel_files = shard_list(mel_files, rank, world)
+  synth = Synthesizer(ckpt, custom_hparams=split_hparams_string(ns.custom_hparams), device=device)
+  for mel_path in mel_files:
+    wav_path = out_dir / mel_path.relative_to(ns.folder).parent / f"{mel_path.stem}.wav"
+    if wav_path.exists() and not ns.overwrite:
+      continue
+    mel = torch.FloatTensor(np.load(mel_path)).unsqueeze(0)
+    res = synth.infer(mel, sigma=ns.sigma, denoiser_strength=ns.denoiser_strength, seed=seed)
+    wav_path.parent.mkdir(parents=True, exist_ok=True)
+    float_to_wav(normalize_wav(res.wav_denoised), wav_path, sample_rate=res.sampling_rate)
+  return True
+
+
+def main(argv=None) -> int:
+  ns = build_parser().parse_args(argv)
+  ok = synthesize(ns) if ns.command == "synthesize" else False
+  return 0 if ok else 1
+
+
+if __name__ == "__main__":
+  sys.exit(main())
