@@ -41,7 +41,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
   for line in res.stderr.splitlines():
     if "Function Name:" in line:
       name = line.split("Function Name:")[1].split("[")[0].strip()
-    for key in ("VGPRs Spill:", "SGPRs Spill:", "ScratchSize [bytes/lane]:"):
+    # SGPR spills go to VGPR lanes (v_writelane), never to memory: tolerated.  VGPR spills / scratch are not.
+    for key in ("VGPRs Spill:", "ScratchSize [bytes/lane]:"):
       if key in line and name:
         val = int(line.split(key)[1].split("[")[0].strip())
         if val != 0:

@@ -63,14 +63,24 @@ __device__ __forceinline__ void gload16(half8& dst, const void* sbase, unsigned 
     __builtin_amdgcn_sched_barrier(0);                                                           \
     unsigned long long _t;                                                                       \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                   \
-    if (a.stamps && a.has_res && tid == 0) a.stamps[(size_t)tile * 8 + (i)] = _t;                        \
+    if (a.stamps && HAS_RES && tid == 0) a.stamps[(size_t)tile * 8 + (i)] = _t;                        \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
 #else
 #define WG_STAMP(i) do {} while (0)
 #endif
 
-constexpr bool kPersistent = false;   // see the note at the tile loop of wn_layer_kernel
+constexpr bool kPersistent = true;    // cross-tile prefetch inside a workgroup (see the tile loop of wn_layer_kernel)
+#ifdef WG_DBG_NO_XTILE_DMA
+constexpr bool kXTileDMA = false;
+#else
+constexpr bool kXTileDMA = kPersistent;
+#endif
+// The next tile's A fragments are NOT prefetched under the epilogue: between such an inline-asm load and its wait
+// lies a long stretch of compiler-scheduled code, and hipcc moved the still-in-flight destination registers
+// there (wrong results).  They are loaded at the tile top instead (~1 L2 latency exposed per tile).
+constexpr bool kXTileA = false;
+constexpr int kTilesPerWG = 2;        // tiles per workgroup, fully unrolled
 
 template <int C> struct WnCfg {
   static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
@@ -95,7 +105,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // Wave w owns gate channels [32*MB*w, 32*MB*(w+1)): its A (weight) fragments are private, so they go L2 -> VGPR
 // directly (pre-packed in fragment order, 1 KiB per wave-load); the B tile (activations) is shared by all waves
 // and goes HBM/L2 -> LDS by LDS-DMA.  All VMEM of the K loop is hand-counted (see glds16).
-template <int C, int NW, int BN>
+template <int C, int NW, int BN, bool HAS_RES>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
   constexpr int MB = C / (32 * NW);      // 32-channel blocks per wave
   constexpr int MT = 2 * MB;             // M tiles per wave: MB tanh blocks, then MB sigmoid blocks
@@ -116,21 +126,33 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   char* const sActs = smem + 2 * BT_BYTES;   // BN x ACT_ROW
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ln = lane & 31;
-  const int lh = lane >> 5;
+  // Lane-derived values are re-derived from an opaque copy of tid at the top of every tile (set_lane_ids), so
+  // hipcc cannot share address arithmetic between the unrolled tile bodies and keep it live across a whole tile.
+  int lane = tid & 63, ln = lane & 31, lh = lane >> 5;
 
   // LDS-DMA one B tile: piece idx = row*8 + physical 16-B chunk; logical chunk = phys ^ ((row>>1)&7)
   // (LDS destination is lane-linear, so the bank swizzle is applied to the SOURCE address).
   // Per-lane source offsets are the same for every K-step; only the scalar tile base moves.
   unsigned pvoff[NG];
+  int swB;
+  unsigned a_voff;
+  auto set_lane_ids = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    lane = t & 63;
+    ln = lane & 31;
+    lh = lane >> 5;
+    swB = (ln >> 1) & 7;
+    a_voff = lane * 16;
 #pragma unroll
-  for (int i = 0; i < NG; ++i) {
-    const int idx = i * NTHREADS + tid;
-    const int row = idx >> 3, pc = idx & 7;
-    pvoff[i] = row * 128 + ((pc ^ ((row >> 1) & 7)) << 4);
-  }
+    for (int i = 0; i < NG; ++i) {
+      const int idx = i * NTHREADS + t;
+      const int row = idx >> 3, pc = idx & 7;
+      pvoff[i] = row * 128 + ((pc ^ ((row >> 1) & 7)) << 4);
+    }
+  };
+  set_lane_ids();
   const unsigned sB_addr = (unsigned)(size_t)WG_LPTR(sB);
   const int R = a.g.R;
   const int nK = 3 * CC + a.ns_chunks;
@@ -148,7 +170,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
            __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16));
 #endif
   };
-  const int swB = (ln >> 1) & 7;
   auto read_B = [&](const char* buf, int nt, int k16) -> half8 {
 #ifdef WG_DBG_NO_LDSREAD
     half8 z; asm volatile("" : "=v"(z)); return z;
@@ -159,7 +180,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   };
   // A fragments: packed [2*nK half K-steps][wave][MT][2 k16][64 lanes][8].  q[g][mt] holds the fragment of
   // k16 sub-step g (0..3) of the current K-step; one fragment = one 1 KiB wave-load straight from L2.
-  const unsigned a_voff = lane * 16;
   auto load_Aq = [&](int ks, int g, int mt, half8& dst) {
 #ifdef WG_DBG_A_SAME   // timing experiment only: every step re-reads fragment block 0 (L1-resident)
     ks = 0;
@@ -177,18 +197,20 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     return b * a.g.Lp + a.g.G + (tile - b * a.tiles_per_utt) * BN;
   };
 
-  // ---- persistent workgroup: the grid is one workgroup per CU; blocks b and b+8 share an XCD (round-robin
-  // dispatch; speed only), so XCD x owns a contiguous run of time tiles and its workgroups walk it with
-  // stride (blocks on that XCD): tiles that run at the same time are neighbours and re-read each other's
-  // +-dil halo rows from that XCD's L2.
-  int tile, tile_end, tile_step;
+  // ---- tile walk.  Blocks b and b+8 share an XCD (round-robin dispatch; speed only), so XCD label x owns a
+  // contiguous run of time tiles; its blocks take tiles start+idx, start+idx+step, ... (step = blocks on that
+  // label): tiles that run at the same time are neighbours and re-read each other's +-dil halo rows from that L2.
+  // A workgroup processes kTilesPerWG tiles in a FULLY UNROLLED loop: the next tile's first B tile (LDS-DMA) and A
+  // fragments are issued under the current tile's gate / GEMM2 / epilogue, and the workgroup launch cost is paid
+  // once per kTilesPerWG tiles.  (A real persistent loop makes hipcc spill 100+ VGPRs around the back edge.)
+  int tile, tile_end;
+  const int tile_step = gridDim.x >> 3;        // grid is a multiple of 8
   {
-    const int nb = gridDim.x, bid = blockIdx.x, ntl = a.n_tiles;
+    const int bid = blockIdx.x, ntl = a.n_tiles;
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntl >> 3, r = ntl & 7;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     tile_end = start + (xcd < r ? q + 1 : q);
-    tile_step = (nb >> 3) + ((nb & 7) > xcd ? 1 : 0);     // blocks that landed on this XCD label
     tile = start + idx;
   }
 
@@ -208,9 +230,22 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
   __syncthreads();
 
-  // NOTE: written as a persistent loop (grid = #CUs) but launched with one tile per workgroup for now: with
-  // a real trip count hipcc (ROCm 7.2) spills 100+ VGPRs around the loop; with a single trip it allocates 236.
-  if (tile < tile_end) {
+#pragma unroll
+  for (int it = 0; it < kTilesPerWG; ++it, tile += tile_step) {
+    if (tile >= tile_end) break;
+    if (it > 0) {
+      set_lane_ids();
+      if constexpr (!kXTileDMA) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(tile), 0, par, i);
+      }
+      if constexpr (!kXTileA) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+      }
+    }
     const int b = tile / a.tiles_per_utt;
     const int jt = tile - b * a.tiles_per_utt;
     const int r0 = b * a.g.Lp + a.g.G + jt * BN;   // first plane row of this tile
@@ -348,9 +383,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     par = (par + nK) & 1;
     // Next tile's first B tile goes out now, into the LDS buffer the last step did not use (slow waves may
     // still be reading that one); its A fragments follow after the gate -- all land under the phases below.
-    if (next_tile < tile_end) {
+    if constexpr (kXTileDMA) {
+      if (next_tile < tile_end) {
 #pragma unroll
-      for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(next_tile), 0, par, i);
+        for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(next_tile), 0, par, i);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -369,7 +406,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     half8 xres[MB][NT][2];
     half8 a2[MB][PF];
     const half8* const p2 = (const half8*)a.wA2 + (size_t)wave * MB * K2 * 64 + laneo;
-    if (a.has_res) {
+    if constexpr (HAS_RES) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int blk = wave * MB + mb;
@@ -407,7 +444,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     WG_STAMP(3);
     // The accumulators are dead now: room for the next tile's first A fragments.  Unconditional (the weights
     // are the same for every tile) so h0/h1 are plainly dead across the gate above, not "maybe still needed".
-    if constexpr (kPersistent) {
+    if constexpr (kXTileA) {
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -417,7 +454,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 
     // GEMM2 accumulators start from x + b_res (residual add for free, model.py:132)
     f32x16 acc2[MB][NT];
-    if (a.has_res) {
+    if constexpr (HAS_RES) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const float* bp = a.bias2 + (wave * MB + mb) * 32 + 4 * lho;
@@ -450,7 +487,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     if constexpr (kWesEarly) load_wes();                     // issue now, consume after GEMM2
 
     // ---- GEMM2: res rows of this wave (model.py:130-132); acts fragments read one k16 step ahead
-    if (a.has_res) {
+    if constexpr (HAS_RES) {
       half8 bq[2][NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bq[0][nt] = read_acts32(nt, 0);
@@ -504,7 +541,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 
     WG_STAMP(5);
     // ---- x_out = fp16(x + res) for valid columns (rows >= L stay zero: they are other tiles' padding)
-    if (a.has_res) {
+    if constexpr (HAS_RES) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int blk = wave * MB + mb;
@@ -526,23 +563,31 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     }
     WG_STAMP(6);
+    __builtin_amdgcn_sched_barrier(0);   // keep the next tile's prologue (128 accumulator inits) out of this epilogue
   }
 }
 
-template <int C>
-static hipError_t launch_wn_t(const WnLayerArgs& a, hipStream_t s) {
+template <int C, bool HAS_RES>
+static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int BN = WnCfg<C>::BN, NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 2 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int grid = a.n_tiles;   // one tile per workgroup (see the note at the tile loop)
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN>), dim3(grid), dim3(NW * 64), smem, s, a);
+  // kTilesPerWG tiles per workgroup: per XCD label ceil(tiles_on_label / kTilesPerWG) blocks
+  const int per_label = ((a.n_tiles + 7) / 8 + kTilesPerWG - 1) / kTilesPerWG;
+  const int grid = 8 * per_label;
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
+}
+template <int C>
+static hipError_t launch_wn_t(const WnLayerArgs& a, hipStream_t s) {
+  // the last layer of a WN has no residual output (model.py:106-110): separate instantiation
+  return a.has_res ? launch_wn_tt<C, true>(a, s) : launch_wn_tt<C, false>(a, s);
 }
 
 int wn_block_n(int C) {
