@@ -115,7 +115,7 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None
-  if world > 1:
+  if world > 1 or os.environ.get("WG_BENCH_FORCE_DIST"):   # the env var exercises the RCCL path on one GPU
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=dev)
 

@@ -78,10 +78,13 @@ def test_infer_from_weightnorm_checkpoint(name):
   assert rms(out - ref) <= RMS_TOL
 
 
+@pytest.mark.parametrize("force_bn", ["128", "64"])
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (2, 33), (1, 130)])
-def test_infer_ragged_lengths_vs_oracle(B, T):
-  """L = 32*T not a multiple of the 128-column tile; edge tiles, guard rows, batch > 1."""
+def test_infer_ragged_lengths_vs_oracle(B, T, force_bn, monkeypatch):
+  """L = 32*T not a multiple of the 128-column tile; edge tiles, guard rows, batch > 1, several tiles per
+  workgroup; both WN tile widths."""
   from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_FORCE_BN", force_bn)
   hp = HParams(n_channels=64, n_layers=8, n_flows=4, n_early_every=2)
   sd = synthetic.make_state_dict(hp, seed=11)
   mel = synthetic.make_mel(B, T, seed=T)
@@ -92,8 +95,11 @@ def test_infer_ragged_lengths_vs_oracle(B, T):
   assert rms(out - ref) <= RMS_TOL, rms(out - ref)
 
 
-def test_infer_c256_vs_oracle_medium():
+@pytest.mark.parametrize("force_bn", ["128", "64"])
+def test_infer_c256_vs_oracle_medium(force_bn, monkeypatch):
+  """Both WN tile widths (128 columns = default, 64 = small-workload variant) against the oracle."""
   from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_FORCE_BN", force_bn)
   hp = HParams()
   sd = synthetic.make_state_dict(hp, seed=0)
   B, T = 2, 40

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -109,6 +110,7 @@ struct wg_handle {
   size_t off_upw = 0, off_upb = 0;
   std::vector<FlowOffsets> flows;
   int n_cu = 256;         // multiProcessorCount, read in wg_finalize
+  int force_bn = 0;       // WG_FORCE_BN=64|128 (tests): pin the WN tile width instead of choosing by workload size
   unsigned long long* dbg_stamps = nullptr;   // diagnostic builds only
   // profiling
   bool prof = false;
@@ -222,6 +224,7 @@ int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
   h->device = device_id;
   h->NS = c.n_mel_channels * c.n_group;
   h->c_k = ck;
+  if (const char* e = getenv("WG_FORCE_BN")) h->force_bn = atoi(e);
   h->expected.push_back("upsample.weight");
   h->expected.push_back("upsample.bias");
   for (int k = 0; k < c.n_flows; ++k) {
@@ -509,7 +512,11 @@ size_t wg_forward_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frame
 static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*& cur, _Float16*& oth, hipStream_t s) {
   const wg_config& c = h->cfg;
   const int C = c.n_channels;
-  const int BN = wn_block_n(C);
+  int BN = wn_block_n(C);
+  // small workloads: 64-column tiles double the workgroup count when 128-column tiles would leave CUs idle
+  if (BN == 128 && (int64_t)g.B * (g.Ltile / 128) < (int64_t)h->n_cu) BN = 64;
+  if (BN == 128 && h->force_bn == 64) BN = 64;
+  if (h->force_bn == 128 && wn_block_n(C) == 128) BN = 128;
   const FlowOffsets& fo = h->flows[k];
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerOffsets& lo = fo.layers[i];
@@ -533,7 +540,7 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.n_cu = h->n_cu;
     {
       Prof p(h, s, 2);
-      HIP_TRY(launch_wn_layer(a, C, s));
+      HIP_TRY(launch_wn_layer(a, C, BN, s));
     }
     if (a.has_res) std::swap(cur, oth);
   }

@@ -30,12 +30,14 @@ __device__ __forceinline__ float load_io(const void* p, size_t i, int f16) {
 }
 
 // tanh(a) * sigmoid(b)  (model.py:17-19).  The host pre-scales the tanh rows of the GEMM-1 weights/bias by
-// 2*log2(e) and the sigmoid rows by -log2(e), so with u = 2a*log2e, v = -b*log2e:
-//   tanh(a) = 1 - 2/(1 + 2^u),  sigmoid(b) = 1/(1 + 2^v)      (saturates correctly at 2^u, 2^v = 0 or inf)
+// 2*log2(e) and the sigmoid rows by -log2(e), so with u = 2a*log2e, v = -b*log2e, E1 = 2^u, E2 = 2^v:
+//   tanh(a) sigmoid(b) = (E1 - 1) / ((E1 + 1)(1 + E2))        -- two exp2 and ONE reciprocal (transcendentals are
+// quarter rate and dominate the gate).  u is clamped to +-60 (tanh is +-1 to fp32 there) so E1 stays finite and
+// non-zero: E2 = inf then gives 1/inf = 0 and E2 = 0 gives plain tanh, no NaN path.
 __device__ __forceinline__ float gate_act(float u, float v) {
-  const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
-  const float r2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v));
-  return fmaf(-2.0f, r1, 1.0f) * r2;
+  const float e1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(u, -60.0f, 60.0f));
+  const float t = 1.0f + __builtin_amdgcn_exp2f(v);
+  return (e1 - 1.0f) * __builtin_amdgcn_rcpf(fmaf(e1, t, t));
 }
 
 // ---- hand-counted VMEM in the GEMM main loop (cdna_hip_programming.md 5.7): hipcc drains an LDS-DMA before
@@ -81,6 +83,14 @@ constexpr bool kXTileDMA = kPersistent;
 // there (wrong results).  They are loaded at the tile top instead (~1 L2 latency exposed per tile).
 constexpr bool kXTileA = false;
 constexpr int kTilesPerWG = 2;        // tiles per workgroup, fully unrolled
+// Experiment (-DWG_REGSTAGE_B): stage the B tiles of K-steps >= 1 global -> VGPR -> LDS (loaded two steps ahead,
+// ds_write one step ahead, right after the barrier) instead of by LDS-DMA.  Measured SLOWER on MI355X (K loop 59.3k
+// vs 57.6k cycles per tile, launch 0.687 vs 0.670 ms), so LDS-DMA stays the default.
+#ifdef WG_REGSTAGE_B
+constexpr bool kRegStageB = true;
+#else
+constexpr bool kRegStageB = false;
+#endif
 
 template <int C> struct WnCfg {
   static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
@@ -219,6 +229,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
 
   half8 q[4][MT];
+  half8 breg[NG];                            // register-staged B tile (kRegStageB)
   int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
   if (tile < tile_end) {
 #pragma unroll
@@ -281,6 +292,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     //   g=2  slots: read bf[1] <- sub-step 3 ; reload q[1] <- A(ks+1, 1)       (wait q[2] first)
     //   then reload q[2] <- A(ks+1, 2); vmcnt(2*MT): DMA and q[0] landed; lgkmcnt(0); ONE s_barrier.
     // VMEM issue order per step: DMA xNG, q3 xMT, q0 xMT, q1 xMT, q2 xMT -- every wait is a counted vmcnt.
+    if constexpr (kRegStageB) {
+      const char* src1 = kstep_src(r0, 1);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) gload16<0>(breg[i], src1, pvoff[i]);
+    }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -301,28 +317,42 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     // One K-step; MORE = "a next step exists" is a compile-time flag (the last step is peeled) so the body has
     // no branches (so are the first step's missing deferred MFMAs), and the next tile's DMA source is computed
     // once per step in scalar registers.
-    auto kstep = [&](auto more_tag, auto first_tag, auto hi_tag, int ks) {
-      constexpr bool more = decltype(more_tag)::value;
+    auto kstep = [&](auto more_tag, auto more2_tag, auto first_tag, auto hi_tag, int ks) {
+      constexpr bool more = decltype(more_tag)::value;      // step ks+1 exists
+      constexpr bool more2 = decltype(more2_tag)::value;    // step ks+2 exists
       constexpr bool first = decltype(first_tag)::value;
       // Stagger: the two waves of a SIMD (w, w + NW/2) run this loop in lockstep; the upper half takes its
       // VMEM slots half a sub-step later, so one wave's load issue sits beside its partner's MFMAs.
       constexpr int SH = decltype(hi_tag)::value ? NT / 2 : 0;
+      // VMEM ops this step issues for the B operand ahead of the q loads: LDS-DMA pieces of tile ks+1, or
+      // (register staging) the loads of tile ks+2
+      constexpr int NB = kRegStageB ? (more2 ? NG : 0) : (more ? NG : 0);
       const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
       const char* src_next = nullptr;
-      if constexpr (more) src_next = kstep_src(r0, ks + 1);
+      if constexpr (kRegStageB) { if constexpr (more2) src_next = kstep_src(r0, ks + 2); }
+      else { if constexpr (more) src_next = kstep_src(r0, ks + 1); }
       const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
+      if constexpr (kRegStageB && more) {
+        // tile ks+1 (loaded during step ks-1, landed before the barrier) -> its LDS buffer, free since the barrier
+        char* wp = sB + ((ks + 1 + par) & 1) * BT_BYTES + tid * 16;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) *(half8*)(wp + i * NTHREADS * 16) = breg[i];
+      }
       __builtin_amdgcn_sched_barrier(0);
       auto dma_slot = [&](int nt) {
-        if constexpr (more) {
 #pragma unroll
-          for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i)
-            glds16(src_next, pvoff[i], __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16));
+        for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) {
+          if constexpr (kRegStageB) {
+            if constexpr (more2) gload16<0>(breg[i], src_next, pvoff[i]);
+          } else {
+            if constexpr (more) glds16(src_next, pvoff[i], __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16));
+          }
         }
       };
       if constexpr (DEFER) {
-        // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
+        // ---- D: deferred sub-step 3 of step ks-1 + B-operand loads
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           if constexpr (!first) mfma_col(3, nt);
@@ -333,9 +363,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
 #pragma unroll
       for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
-        if (g == 1) wait_vm<more ? 2 * MT + NG : 2 * MT>();      // q[1] landed
-        if (g == 2) wait_vm<more ? NG + 2 * MT : MT>();          // q[2] landed
-        if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
+        if (g == 1) wait_vm<2 * MT + NB>();                          // q[1] landed
+        if (g == 2) wait_vm<NB + MT + (more ? MT : 0)>();            // q[2] landed
+        if (g == 3) wait_vm<more ? 2 * MT : 0>();                    // q[3] landed (no deferral)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           mfma_col(g, nt);
@@ -356,7 +386,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 1, 2, mt, q[2][mt]);
         }
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * MT) : "memory");   // DMA, q[0] landed; reads done
+        // B operand of the next steps and q[0] landed (only q[1], q[2] reloads may be outstanding); own LDS
+        // reads of this buffer and LDS writes of the next one done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * MT) : "memory");
 #ifndef WG_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
@@ -364,10 +396,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     };
     auto kloop = [&](auto hi_tag) {
-      kstep(std::true_type{}, std::true_type{}, hi_tag, 0);    // nK >= 13: first, middle and last steps all exist
+      using T = std::true_type;
+      using F = std::false_type;
+      kstep(T{}, T{}, T{}, hi_tag, 0);            // nK >= 13: first, middle, second-last and last steps all exist
 #pragma clang loop unroll(disable)
-      for (int ks = 1; ks < nK - 1; ++ks) kstep(std::true_type{}, std::false_type{}, hi_tag, ks);
-      kstep(std::false_type{}, std::false_type{}, hi_tag, nK - 1);
+      for (int ks = 1; ks < nK - 2; ++ks) kstep(T{}, T{}, F{}, hi_tag, ks);
+      kstep(T{}, F{}, F{}, hi_tag, nK - 2);
+      kstep(F{}, F{}, F{}, hi_tag, nK - 1);
     };
 #ifdef WG_STAGGER   // experiment: two copies of the loop push hipcc into spilling (26 VGPRs @C=256) -- off
     if (wave >= NW / 2) kloop(std::true_type{}); else kloop(std::false_type{});
@@ -567,9 +602,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   }
 }
 
-template <int C, bool HAS_RES>
+template <int C, int BN, bool HAS_RES>
 static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
-  constexpr int BN = WnCfg<C>::BN, NW = WnCfg<C>::NW;
+  constexpr int NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 2 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
@@ -585,9 +620,14 @@ static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 template <int C>
-static hipError_t launch_wn_t(const WnLayerArgs& a, hipStream_t s) {
-  // the last layer of a WN has no residual output (model.py:106-110): separate instantiation
-  return a.has_res ? launch_wn_tt<C, true>(a, s) : launch_wn_tt<C, false>(a, s);
+static hipError_t launch_wn_t(const WnLayerArgs& a, int bn, hipStream_t s) {
+  // the last layer of a WN has no residual output (model.py:106-110): separate instantiation.
+  // bn = 64: small-batch variant (twice the tiles; used when 128-column tiles would leave CUs idle).
+  if (bn == 64) return a.has_res ? launch_wn_tt<C, 64, true>(a, s) : launch_wn_tt<C, 64, false>(a, s);
+  if constexpr (WnCfg<C>::BN == 128) {
+    if (bn == 128) return a.has_res ? launch_wn_tt<C, 128, true>(a, s) : launch_wn_tt<C, 128, false>(a, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 int wn_block_n(int C) {
@@ -609,12 +649,12 @@ int wn_waves(int C) {
   return 0;
 }
 
-hipError_t launch_wn_layer(const WnLayerArgs& a, int C, hipStream_t s) {
+hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s) {
   switch (C) {
-    case 64: return launch_wn_t<64>(a, s);
-    case 128: return launch_wn_t<128>(a, s);
-    case 256: return launch_wn_t<256>(a, s);
-    case 512: return launch_wn_t<512>(a, s);
+    case 64: return launch_wn_t<64>(a, bn, s);
+    case 128: return launch_wn_t<128>(a, bn, s);
+    case 256: return launch_wn_t<256>(a, bn, s);
+    case 512: return launch_wn_t<512>(a, bn, s);
   }
   return hipErrorInvalidValue;
 }

@@ -108,8 +108,8 @@ struct FlowArgs {
 // launch wrappers (kernels.hip)
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
-hipError_t launch_wn_layer(const WnLayerArgs& a, int C, hipStream_t s);
-int wn_block_n(int C);   // BN used for channel count C
+hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // bn = 128 (default) or 64
+int wn_block_n(int C);   // default BN for channel count C
 int wn_waves(int C);     // waves per workgroup for channel count C
 
 }  // namespace wg
