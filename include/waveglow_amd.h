@@ -107,6 +107,14 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
                float* log_det_W, int32_t B, int32_t n_frames, int32_t audio_len, int32_t io_dtype,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* WaveGlowLoss.forward (src/waveglow/train.py:31-45) on the outputs of wg_forward:
+ *   loss = (sum z^2 / (2 sigma^2) - sum_k sum log_s[k] - sum_k log_det_W[k]) / z_elems      (z_elems = B*n_group*L)
+ * z, log_s[k]: device fp32 with z_elems / log_s_elems[k] elements; log_det_W: n_flows HOST floats;
+ * loss_out: DEVICE float; workspace: >= 16 bytes of device memory.  Enqueue-only; sums accumulate in fp64. */
+int wg_loss(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
+            const float* log_det_W, float sigma, float* loss_out, void* workspace, size_t workspace_bytes,
+            void* stream);
+
 /* Algorithmic MACs per group-timestep (8 samples) of one infer pass, as SURVEY.md section 8(d) counts
  * them (for roofline reporting). */
 double wg_macs_per_group_step(const wg_handle* h);

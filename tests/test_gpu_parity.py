@@ -157,6 +157,15 @@ def test_forward_golden(name):
     assert rms(ls.cpu() - ref) <= 1e-3, (k, rms(ls.cpu() - ref))
   ld = np.array([float(x) for x in log_det], dtype=np.float32)
   np.testing.assert_allclose(ld, c.npz["fwd_log_det"], atol=2e-3)
+  # WaveGlowLoss (train.py:31-45) on the device: on the reference's own forward outputs it must reproduce the
+  # reference's loss (fp64 accumulation here vs fp32 there), and on ours it must stay within the flow's tolerance
+  from waveglow_amd.model import WaveGlowLoss
+  ref_out = (z_ref.cuda(), [torch.from_numpy(c.npz[f"fwd_log_s_{k}"]).cuda() for k in range(len(log_s))],
+             [torch.tensor(float(v)) for v in c.npz["fwd_log_det"]])
+  loss_ref_inputs = float(WaveGlowLoss(1.0)(ref_out, None))
+  assert abs(loss_ref_inputs - float(c.npz["fwd_loss"])) <= 2e-6 * max(1.0, abs(float(c.npz["fwd_loss"])))
+  loss_ours = float(WaveGlowLoss(1.0)((z, log_s, log_det), None))
+  assert abs(loss_ours - float(c.npz["fwd_loss"])) <= 2e-3
 
 
 def test_flow_round_trip_full_size():

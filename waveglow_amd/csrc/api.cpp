@@ -730,6 +730,25 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   return WG_OK;
 }
 
+int wg_loss(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
+            const float* log_det_W, float sigma, float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!z || !log_s || !log_s_elems || !log_det_W || !loss_out || !workspace) return fail(WG_ERR_INVALID, "null buffer");
+  if (z_elems < 1 || n_flows < 1 || !(sigma > 0.f)) return fail(WG_ERR_INVALID, "bad sizes/sigma");
+  if (workspace_bytes < 16) return fail(WG_ERR_WORKSPACE, "workspace %zu < required 16", workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  double* acc = (double*)workspace;
+  HIP_TRY(hipMemsetAsync(acc, 0, 16, s));
+  HIP_TRY(launch_reduce_sum(z, (size_t)z_elems, 1, acc, s));                              // sum z*z      train.py:43
+  double log_det_total = 0.0;
+  for (int k = 0; k < n_flows; ++k) {
+    if (!log_s[k] || log_s_elems[k] < 1) return fail(WG_ERR_INVALID, "bad log_s[%d]", k);
+    HIP_TRY(launch_reduce_sum(log_s[k], (size_t)log_s_elems[k], 0, acc + 1, s));          // sum log_s    train.py:36-40
+    log_det_total += (double)log_det_W[k];                                                // train.py:37,41
+  }
+  HIP_TRY(launch_loss_final(acc, log_det_total, sigma, (double)z_elems, loss_out, s));    // train.py:43-44
+  return WG_OK;
+}
+
 double wg_macs_per_group_step(const wg_handle* h) {
   if (!h) return 0.0;
   const wg_config& c = h->cfg;

@@ -931,4 +931,47 @@ hipError_t launch_flow(const FlowArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// =============================================================================================
+// WaveGlowLoss (src/waveglow/train.py:31-45): sum z^2 and sum log_s on the device (fp64 accumulation: block tree +
+// one atomic per block), then loss = (sum z^2 / (2 sigma^2) - sum log_s - sum log_det_W) / (B * 8 * L).
+// =============================================================================================
+template <bool SQUARE>
+__global__ void __launch_bounds__(256) reduce_sum_kernel(const float* __restrict__ x, size_t n, double* acc) {
+  double s = 0.0;
+  const size_t n4 = n / 4;
+  const float4* x4 = (const float4*)x;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    if (SQUARE) s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    else s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = x[n4 * 4 + threadIdx.x];
+    s += SQUARE ? (double)v * v : (double)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void loss_final_kernel(const double* acc, double log_det_total, float sigma, double denom, float* out) {
+  *out = (float)((acc[0] / (2.0 * (double)sigma * (double)sigma) - acc[1] - log_det_total) / denom);
+}
+
+hipError_t launch_reduce_sum(const float* x, size_t n, int square, double* acc, hipStream_t s) {
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  if (square) hipLaunchKernelGGL(reduce_sum_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, n, acc);
+  else hipLaunchKernelGGL(reduce_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, n, acc);
+  return hipGetLastError();
+}
+hipError_t launch_loss_final(const double* acc, double log_det_total, float sigma, double denom, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, s, acc, log_det_total, sigma, denom, out);
+  return hipGetLastError();
+}
+
 }  // namespace wg

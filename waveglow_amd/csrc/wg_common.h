@@ -112,4 +112,7 @@ hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s); 
 int wn_block_n(int C);   // default BN for channel count C
 int wn_waves(int C);     // waves per workgroup for channel count C
 
+hipError_t launch_reduce_sum(const float* x, size_t n, int square, double* acc, hipStream_t s);
+hipError_t launch_loss_final(const double* acc, double log_det_total, float sigma, double denom, float* out, hipStream_t s);
+
 }  // namespace wg

@@ -255,3 +255,30 @@ class WaveGlow(nn.Module):
         wnet.in_layers = nn.ModuleList([rp(m, "weight") for m in wnet.in_layers])
         wnet.res_skip_layers = nn.ModuleList([rp(m, "weight") for m in wnet.res_skip_layers])
     return model
+
+
+class WaveGlowLoss(nn.Module):
+  """src/waveglow/train.py:26-45: NLL of the flow, computed by the HIP library (``wg_loss``) on the tuple that
+  ``WaveGlow.forward`` returns.  ``y`` is ignored, as in the reference (train.py:31-32).  No autograd."""
+
+  def __init__(self, sigma: float = 1.0):
+    super().__init__()
+    self.sigma = sigma
+
+  def forward(self, y_pred, y=None):
+    z, log_s_list, log_det_W_list = y_pred
+    if z.device.type != "cuda":
+      raise _lib.WgError("WaveGlowLoss runs on the GPU library only")
+    lib = _lib.load()
+    z32 = z.float().contiguous()
+    ls32 = [t.float().contiguous() for t in log_s_list]
+    n = len(ls32)
+    ld = (C.c_float * n)(*[float(x) for x in log_det_W_list])
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ls32])
+    sizes = (C.c_int64 * n)(*[t.numel() for t in ls32])
+    out = torch.empty((), dtype=torch.float32, device=z.device)
+    ws = torch.empty(16, dtype=torch.uint8, device=z.device)
+    stream = torch.cuda.current_stream(z.device).cuda_stream
+    _lib.check(lib.wg_loss(z32.data_ptr(), z32.numel(), ptrs, sizes, n, ld, float(self.sigma), out.data_ptr(),
+                           ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+    return out
