@@ -47,7 +47,7 @@ def test_create_validates_configuration(lib):
   # algorithmic MACs per group-timestep, SURVEY.md section 8(d): 81 235 408 @ C=256
   assert int(lib.wg_macs_per_group_step(h)) == 81235408
   # workspace sizing is pure host arithmetic
-  assert lib.wg_infer_workspace_bytes(h, 16, 864) > 16 * 27648 * (640 + 512) * 2
+  assert lib.wg_infer_workspace_bytes(h, 16, 864) > 16 * 27648 * (2 * 256 * 2 + 64)   # two x planes + Z + OUT
   assert lib.wg_infer_workspace_bytes(h, 0, 864) == 0
   # infer before finalize -> state error, not a crash
   import ctypes

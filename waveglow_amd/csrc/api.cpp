@@ -107,7 +107,8 @@ struct wg_handle {
   bool finalized = false;
   char* d_blob = nullptr;
   size_t blob_bytes = 0;
-  size_t off_upw = 0, off_upb = 0;
+  char* d_cond = nullptr;   // derived: folded cond_layer o upsample A fragments [flow][layer][phase]...
+  size_t cond_layer_bytes = 0, cond_flow_bytes = 0;
   std::vector<FlowOffsets> flows;
   int n_cu = 256;         // multiProcessorCount, read in wg_finalize
   int force_bn = 0;       // WG_FORCE_BN=64|128 (tests): pin the WN tile width instead of choosing by workload size
@@ -135,32 +136,33 @@ std::vector<int> flow_channels(const wg_config& c) {
 
 bool is_early(const wg_config& c, int k) { return k % c.n_early_every == 0 && k > 0; }
 
-RowGeom make_geom(const wg_config& c, int B, int L) {
+RowGeom make_geom(const wg_config& c, int B, int L, int T) {
   RowGeom g;
   g.B = B;
   g.L = L;
-  g.Ltile = (L + 127) / 128 * 128;
-  g.G = 128;
-  while (g.G < (1 << (c.n_layers - 1))) g.G *= 2;
-  g.Lp = g.G + g.Ltile + g.G;
-  g.R = B * g.Lp;
+  g.F = (L + kPhases - 1) / kPhases;
+  g.Gf = 4;                                  // (phase + dilation) >> 5 <= 4 for dilation <= 128 (n_layers <= 8)
+  g.Fp = g.Gf + g.F + g.Gf;
+  g.Rp = (B * g.Fp + 127) / 128 * 128;
+  g.R = kPhases * g.Rp + 2 * kRowPad;
+  g.T = T;
   return g;
 }
 
 struct Workspace {
-  _Float16 *S, *X0, *X1;
+  _Float16 *melT, *X0, *X1;
   float *Z, *OUT;
   size_t bytes;
-  size_t x_bytes, s_bytes;
+  size_t x_bytes, mel_bytes;
 };
 
 Workspace carve(const wg_handle* h, const RowGeom& g, char* base) {
   Workspace w;
   size_t off = 0;
   const int C = h->cfg.n_channels;
-  w.s_bytes = align_up((size_t)h->NS * g.R * 2);
+  w.mel_bytes = align_up((size_t)(3 + g.B * (g.T + 6)) * h->cfg.n_mel_channels * 2);
   w.x_bytes = align_up((size_t)C * g.R * 2);
-  w.S = (_Float16*)(base + off); off += w.s_bytes;
+  w.melT = (_Float16*)(base + off); off += w.mel_bytes;
   w.X0 = (_Float16*)(base + off); off += w.x_bytes;
   w.X1 = (_Float16*)(base + off); off += w.x_bytes;
   w.Z = (float*)(base + off); off += align_up((size_t)g.B * g.L * 8 * 4);
@@ -173,6 +175,10 @@ const HostTensor* find(const wg_handle* h, const std::string& name) {
   auto it = h->tensors.find(name);
   return it == h->tensors.end() ? nullptr : &it->second;
 }
+
+// WG_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault localisation only)
+static bool dbg_sync() { static int v = -1; if (v < 0) { const char* e = getenv("WG_DEBUG_SYNC"); v = e && *e == '1'; } return v == 1; }
+#define WG_DBG(stream, what) do { if (dbg_sync()) { hipError_t _e = hipStreamSynchronize(stream); fprintf(stderr, "[wg] %s -> %s\n", what, hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 struct Prof {
   wg_handle* h;
@@ -250,6 +256,7 @@ int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
 int wg_destroy(wg_handle* h) {
   if (!h) return WG_OK;
   if (h->d_blob) hipFree(h->d_blob);
+  if (h->d_cond) hipFree(h->d_cond);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   delete h;
   return WG_OK;
@@ -298,7 +305,7 @@ int wg_finalize(wg_handle* h) {
   if (!h) return fail(WG_ERR_INVALID, "null handle");
   const wg_config& c = h->cfg;
   const int C = c.n_channels, M = c.n_mel_channels, NS = h->NS, NL = c.n_layers;
-  const int NW = wn_waves(C), MB = C / (32 * NW), MT = 2 * MB, CC = C / 64, K2 = C / 16, nK = 3 * CC + NS / 64;
+  const int NW = wn_waves(C), MB = C / (32 * NW), MT = 2 * MB, CC = C / 64, K2 = C / 16, nKx = 3 * CC;
   std::vector<char> blob;
   auto reserve = [&](size_t bytes) {
     size_t off = align_up(blob.size());
@@ -306,31 +313,10 @@ int wg_finalize(wg_handle* h) {
     return off;
   };
   int rc;
-  // ---- upsample: w_p[t'][j][i][o*8+g] = W[i][o][8t'+g+256j]   (ConvTranspose1d weight is [in][out][k])
+  // ---- upsample weights: folded into the conditioning GEMM on the device below (cond_fold_kernel)
   const HostTensor *upw, *upb;
   if ((rc = check_shape(h, "upsample.weight", {M, M, c.upsample_kernel}, &upw))) return rc;
   if ((rc = check_shape(h, "upsample.bias", {M}, &upb))) return rc;
-  {
-    // A fragments [32 t'][NS/64 cs][2 mb][M/4 k16][64 lanes][8]: row r of block (cs,mb) is channel
-    // ch = cs*64 + mb*32 + r = o*8+g; k = j*M + i  <->  W[i][o][8t'+g+256j]
-    const int NSC = M / 8, KS = M / 4, KPJ = M / 16;
-    h->off_upw = reserve((size_t)32 * NSC * 2 * KS * 64 * 8 * 2);
-    _Float16* wp = (_Float16*)(blob.data() + h->off_upw);
-    for (int tp = 0; tp < 32; ++tp)
-      for (int cs = 0; cs < NSC; ++cs)
-        for (int mb = 0; mb < 2; ++mb)
-          for (int k = 0; k < KS; ++k)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int r = lane & 31, hh = lane >> 5;
-              const int ch = cs * 64 + mb * 32 + r, o = ch >> 3, g = ch & 7;
-              const int j = k / KPJ, i0 = (k % KPJ) * 16 + 8 * hh;
-              _Float16* d = wp + ((((size_t)(tp * NSC + cs) * 2 + mb) * KS + k) * 64 + lane) * 8;
-              for (int e = 0; e < 8; ++e)
-                d[e] = (_Float16)upw->data[((size_t)(i0 + e) * M + o) * c.upsample_kernel + 8 * tp + g + 256 * j];
-            }
-    h->off_upb = reserve((size_t)M * 4);
-    memcpy(blob.data() + h->off_upb, upb->data.data(), (size_t)M * 4);
-  }
   h->flows.assign(c.n_flows, FlowOffsets());
   for (int k = 0; k < c.n_flows; ++k) {
     FlowOffsets& fo = h->flows[k];
@@ -388,12 +374,12 @@ int wg_finalize(wg_handle* h) {
       if ((rc = check_shape(h, p + "in_layers." + is + ".bias", {2 * C}, &bin))) return rc;
       if ((rc = check_shape(h, p + "res_skip_layers." + is + ".weight", {RS, C, 1}, &wrs))) return rc;
       if ((rc = check_shape(h, p + "res_skip_layers." + is + ".bias", {RS}, &brs))) return rc;
-      // GEMM1 A fragments [2*nK half K-steps][NW][MT][2 k16][64 lanes][8]; wave w owns 32-channel blocks
+      // GEMM1 tap A fragments [2*3C/64 half K-steps][NW][MT][2 k16][64 lanes][8]; wave w owns 32-channel blocks
       // w*MB .. w*MB+MB-1: M-tiles mt < MB are their tanh rows, mt >= MB their sigmoid rows (+C)
-      lo.wA1 = reserve((size_t)nK * 2 * NW * MT * 2 * 64 * 8 * 2);
+      lo.wA1 = reserve((size_t)nKx * 2 * NW * MT * 2 * 64 * 8 * 2);
       {
         _Float16* dst = (_Float16*)(blob.data() + lo.wA1);
-        for (int u = 0; u < 2 * nK; ++u)
+        for (int u = 0; u < 2 * nKx; ++u)
           for (int w = 0; w < NW; ++w)
             for (int mt = 0; mt < MT; ++mt)
               for (int k2 = 0; k2 < 2; ++k2)
@@ -406,24 +392,22 @@ int wg_finalize(wg_handle* h) {
                   _Float16* d = dst + (((((size_t)u * NW + w) * MT + mt) * 2 + k2) * 64 + lane) * 8;
                   for (int j = 0; j < 8; ++j) {
                     const int kk = k16 * 16 + 8 * hh + j;
-                    float v;
-                    if (ksx < 3 * CC) {
-                      const int tap = ksx / CC, cc = ksx % CC;
-                      const int ch = pos_to_chan(cc * 64 + kk);
-                      v = win->data[((size_t)m * C + ch) * 3 + tap];
-                    } else {
-                      const int sch = pos_to_chan((ksx - 3 * CC) * 64 + kk);   // spect planes are position-major too
-                      v = wcond->data[((size_t)(2 * C * i + m)) * NS + sch];
-                    }
-                    d[j] = (_Float16)(v * rs);
+                    const int tap = ksx / CC, cc = ksx % CC;
+                    const int ch = pos_to_chan(cc * 64 + kk);
+                    d[j] = (_Float16)(win->data[((size_t)m * C + ch) * 3 + tap] * rs);
                   }
                 }
       }
       lo.bias1 = reserve((size_t)2 * C * 4);
       {
         float* b1 = (float*)(blob.data() + lo.bias1);
-        for (int m = 0; m < 2 * C; ++m)
-          b1[m] = (bin->data[m] + bcond->data[2 * C * i + m]) * (m < C ? kTanhScale : kSigmScale);
+        for (int m = 0; m < 2 * C; ++m) {
+          // constant part of the folded conditioning: W_cond . (upsample bias broadcast over the 8 group phases)
+          double cb = 0.0;
+          const float* wr = &wcond->data[((size_t)(2 * C * i + m)) * NS];
+          for (int sch = 0; sch < NS; ++sch) cb += (double)wr[sch] * upb->data[sch >> 3];
+          b1[m] = (float)((bin->data[m] + bcond->data[2 * C * i + m] + cb) * (m < C ? kTanhScale : kSigmScale));
+        }
       }
       // GEMM2 (res) A fragments [NW][MB][K2][64][8], bias2
       lo.wA2 = reserve((size_t)NW * MB * K2 * 64 * 8 * 2);
@@ -492,6 +476,32 @@ int wg_finalize(wg_handle* h) {
   HIP_TRY(hipMalloc((void**)&h->d_blob, blob.size()));
   HIP_TRY(hipMemcpy(h->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   h->blob_bytes = blob.size();
+  // ---- derived weights: cond_layer o upsample, one matrix per (flow, layer, phase), built on the device
+  {
+    if (h->d_cond) {
+      HIP_TRY(hipFree(h->d_cond));
+      h->d_cond = nullptr;
+    }
+    const int n_half = 2 * (M / 16);
+    h->cond_layer_bytes = (size_t)kPhases * n_half * NW * MT * 2 * 64 * 8 * 2;
+    h->cond_flow_bytes = h->cond_layer_bytes * NL;
+    HIP_TRY(hipMalloc((void**)&h->d_cond, h->cond_flow_bytes * c.n_flows));
+    float *d_wc = nullptr, *d_up = nullptr;
+    const size_t wc_bytes = (size_t)2 * C * NL * NS * 4, up_bytes = (size_t)M * M * c.upsample_kernel * 4;
+    HIP_TRY(hipMalloc((void**)&d_wc, wc_bytes));
+    HIP_TRY(hipMalloc((void**)&d_up, up_bytes));
+    HIP_TRY(hipMemcpy(d_up, upw->data.data(), up_bytes, hipMemcpyHostToDevice));
+    for (int k = 0; k < c.n_flows; ++k) {
+      const HostTensor* wcond = find(h, "WN." + std::to_string(k) + ".cond_layer.weight");
+      HIP_TRY(hipMemcpy(d_wc, wcond->data.data(), wc_bytes, hipMemcpyHostToDevice));
+      HIP_TRY(launch_cond_fold(d_wc, d_up, (_Float16*)(h->d_cond + h->cond_flow_bytes * k), C, NW, M, NL,
+                               c.upsample_kernel, kTanhScale, kSigmScale, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      if (dbg_sync()) { fprintf(stderr, "[wg] cond_fold flow %d ok\n", k); fflush(stderr); }
+    }
+    HIP_TRY(hipFree(d_wc));
+    HIP_TRY(hipFree(d_up));
+  }
   h->finalized = true;
   return WG_OK;
 }
@@ -499,13 +509,13 @@ int wg_finalize(wg_handle* h) {
 size_t wg_infer_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames) {
   if (!h || B < 1 || n_frames < 1) return 0;
   const int L = n_frames * h->cfg.upsample_stride / h->cfg.n_group;
-  RowGeom g = make_geom(h->cfg, B, L);
+  RowGeom g = make_geom(h->cfg, B, L, n_frames);
   return carve(h, g, nullptr).bytes;
 }
 
 size_t wg_forward_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
   if (!h || B < 1 || n_frames < 1 || audio_len < h->cfg.n_group || audio_len % h->cfg.n_group) return 0;
-  RowGeom g = make_geom(h->cfg, B, audio_len / h->cfg.n_group);
+  RowGeom g = make_geom(h->cfg, B, audio_len / h->cfg.n_group, n_frames);
   return carve(h, g, nullptr).bytes;
 }
 
@@ -514,7 +524,7 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
   const int C = c.n_channels;
   int BN = wn_block_n(C);
   // small workloads: 64-column tiles double the workgroup count when 128-column tiles would leave CUs idle
-  if (BN == 128 && (int64_t)g.B * (g.Ltile / 128) < (int64_t)h->n_cu) BN = 64;
+  if (BN == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)h->n_cu) BN = 64;
   if (BN == 128 && h->force_bn == 64) BN = 64;
   if (h->force_bn == 128 && wn_block_n(C) == 128) BN = 128;
   const FlowOffsets& fo = h->flows[k];
@@ -523,7 +533,8 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     WnLayerArgs a;
     a.x_in = cur;
     a.x_out = oth;
-    a.spect = w.S;
+    a.melT = w.melT;
+    a.wA1c = (const _Float16*)(h->d_cond + h->cond_flow_bytes * k + h->cond_layer_bytes * i);
     a.wA1 = (const _Float16*)(h->d_blob + lo.wA1);
     a.bias1 = (const float*)(h->d_blob + lo.bias1);
     a.wA2 = (const _Float16*)(h->d_blob + lo.wA2);
@@ -532,16 +543,18 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.out = w.OUT;
     a.g = g;
     a.dil = 1 << i;
-    a.ns_chunks = h->NS / 64;
+    a.n_cond_steps = c.n_mel_channels / 16;
+    a.M = c.n_mel_channels;
     a.has_res = i < c.n_layers - 1;
-    a.tiles_per_utt = g.Ltile / BN;
-    a.n_tiles = g.B * a.tiles_per_utt;
+    a.tiles_per_phase = g.Rp / BN;
+    a.n_tiles = kPhases * a.tiles_per_phase;
     a.stamps = h->dbg_stamps;
     a.n_cu = h->n_cu;
     {
       Prof p(h, s, 2);
       HIP_TRY(launch_wn_layer(a, C, BN, s));
     }
+    WG_DBG(s, "wn_layer");
     if (a.has_res) std::swap(cur, oth);
   }
   return WG_OK;
@@ -561,32 +574,29 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
   if (n_z_early != n_early || (n_early && !z_early)) return fail(WG_ERR_INVALID, "expected %d early-noise tensors", n_early);
   const int L = n_frames * c.upsample_stride / c.n_group;
   if ((int64_t)B * L * 8 >= (1ll << 31)) return fail(WG_ERR_INVALID, "batch too large for 32-bit row indexing");
-  RowGeom g = make_geom(c, B, L);
+  RowGeom g = make_geom(c, B, L, n_frames);
   Workspace w = carve(h, g, (char*)workspace);
   if (w.bytes > workspace_bytes) return fail(WG_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.bytes);
-  if ((size_t)c.n_channels * g.R * 2 >= (1ull << 32)) return fail(WG_ERR_INVALID, "plane too large");
+  if ((size_t)g.R * 128 >= (1ull << 32)) return fail(WG_ERR_INVALID, "plane too large for 32-bit offsets");
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_channels;
   {
     Prof p(h, s, 3);
     // guard rows / rows >= L of both x planes must read as zero padding (model.py:98-102)
     HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes, s));
-    HIP_TRY(hipMemsetAsync(w.S, 0, w.s_bytes, s));
   }
   {
-    UpsampleArgs u;
+    MelPackArgs u;
     u.mel = mel;
-    u.w = (const _Float16*)(h->d_blob + h->off_upw);
-    u.bias = (const float*)(h->d_blob + h->off_upb);
-    u.spect = w.S;
-    u.g = g;
+    u.melT = w.melT;
+    u.B = B;
     u.M = c.n_mel_channels;
     u.T = n_frames;
     u.io_f16 = io_dtype == WG_F16;
-    u.n_q = (8 * L + 255) / 256;
     Prof p(h, s, 0);
-    HIP_TRY(launch_upsample(u, s));
+    HIP_TRY(launch_mel_pack(u, s));
   }
+  WG_DBG(s, "mel_pack");
   _Float16 *cur = w.X0, *oth = w.X1;
   int ze_idx = 0;
   auto base_flow_args = [&]() {
@@ -615,6 +625,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
     Prof p(h, s, 1);
     HIP_TRY(launch_flow(f, s));
   }
+  WG_DBG(s, "flow");
   for (int k = c.n_flows - 1; k >= 0; --k) {
     int rc = run_wn(h, k, g, w, cur, oth, s);
     if (rc) return rc;
@@ -643,6 +654,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
     Prof p(h, s, 1);
     HIP_TRY(launch_flow(f, s));
   }
+  WG_DBG(s, "flow");
   return WG_OK;
 }
 
@@ -660,28 +672,25 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   if ((int64_t)(n_frames - 1) * c.upsample_stride + c.upsample_kernel < audio_len)
     return fail(WG_ERR_INVALID, "upsampled mel (%d frames) shorter than audio (%d)", n_frames, audio_len);
   const int L = audio_len / c.n_group;
-  RowGeom g = make_geom(c, B, L);
+  RowGeom g = make_geom(c, B, L, n_frames);
   Workspace w = carve(h, g, (char*)workspace);
   if (w.bytes > workspace_bytes) return fail(WG_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.bytes);
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_channels;
   for (int k = 0; k < c.n_flows; ++k) log_det_W[k] = (float)((double)B * L * h->flows[k].logdet);   // model.py:63
   HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes, s));
-  HIP_TRY(hipMemsetAsync(w.S, 0, w.s_bytes, s));
   {
-    UpsampleArgs u;
+    MelPackArgs u;
     u.mel = mel;
-    u.w = (const _Float16*)(h->d_blob + h->off_upw);
-    u.bias = (const float*)(h->d_blob + h->off_upb);
-    u.spect = w.S;
-    u.g = g;
+    u.melT = w.melT;
+    u.B = B;
     u.M = c.n_mel_channels;
     u.T = n_frames;
     u.io_f16 = io_dtype == WG_F16;
-    u.n_q = (8 * L + 255) / 256;
     Prof p(h, s, 0);
-    HIP_TRY(launch_upsample(u, s));
+    HIP_TRY(launch_mel_pack(u, s));
   }
+  WG_DBG(s, "mel_pack");
   _Float16 *cur = w.X0, *oth = w.X1;
   int z_ch = 0;
   for (int k = 0; k <= c.n_flows; ++k) {

@@ -44,14 +44,17 @@ __device__ __forceinline__ float gate_act(float u, float v) {
 // any later LDS read and sinks register loads next to their use; both serialise the K loop on memory latency.
 // These loads are invisible to the compiler's s_waitcnt bookkeeping; every consumer sits behind wait_vm0*.
 // LDS-DMA: 64 lanes x 16 B from (sbase + voff) to LDS [lds_addr + lane*16] (M0 saved/restored in-statement).
+// Wait states INSIDE the strings (hipcc pads nothing for inline asm): an SGPR base that a VALU instruction wrote
+// just before -- v_readlane of a spilled SGPR, v_readfirstlane -- needs 5 wait states before a VMEM instruction
+// reads it (observed: memory access fault from a stale base right after an SGPR-spill reload); M0 needs 1.
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void gload16(half8& dst, const void* sbase, unsigned voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
 }
 
 // =============================================================================================
@@ -78,19 +81,13 @@ constexpr bool kXTileDMA = false;
 #else
 constexpr bool kXTileDMA = kPersistent;
 #endif
-// The next tile's A fragments are NOT prefetched under the epilogue: between such an inline-asm load and its wait
-// lies a long stretch of compiler-scheduled code, and hipcc moved the still-in-flight destination registers
-// there (wrong results).  They are loaded at the tile top instead (~1 L2 latency exposed per tile).
-constexpr bool kXTileA = false;
+// (The next tile's A fragments are NOT prefetched under the epilogue: between such an inline-asm load and its
+// wait lies a long stretch of compiler-scheduled code, and hipcc moved the still-in-flight destination registers
+// there -- wrong results.  They are loaded at the tile top: ~1 L2 latency exposed per tile.)
 constexpr int kTilesPerWG = 2;        // tiles per workgroup, fully unrolled
-// Experiment (-DWG_REGSTAGE_B): stage the B tiles of K-steps >= 1 global -> VGPR -> LDS (loaded two steps ahead,
-// ds_write one step ahead, right after the barrier) instead of by LDS-DMA.  Measured SLOWER on MI355X (K loop 59.3k
-// vs 57.6k cycles per tile, launch 0.687 vs 0.670 ms), so LDS-DMA stays the default.
-#ifdef WG_REGSTAGE_B
-constexpr bool kRegStageB = true;
-#else
-constexpr bool kRegStageB = false;
-#endif
+// Tried and measured slower on MI355X, kept out of the source: staging B tiles global -> VGPR -> ds_write instead
+// of LDS-DMA (K loop 59.3k vs 57.6k cycles per tile); offsetting the VMEM slots of the two waves of a SIMD
+// (two copies of the loop made hipcc spill).
 
 template <int C> struct WnCfg {
   static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
@@ -122,6 +119,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NTHREADS = NW * 64;
   constexpr int NT = BN / 32;            // 32-column MFMA tiles per wave
   constexpr int CC = C / 64;             // 64-channel chunks of x
+  constexpr int NKX = 3 * CC;            // K-steps of the three dilated taps
   constexpr int BT_BYTES = BN * 128;     // one staged B tile: BN rows x 64 fp16
   constexpr int ACT_ROW = 2 * C + 16;    // bytes per acts row: +16 B pad => conflict-free b128 reads/writes with
                                          // immediate-offset addressing (one base VGPR per 32-column tile)
@@ -129,7 +127,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NG = BN * 8 / NTHREADS;  // LDS-DMA instructions per wave per B tile
   constexpr int NAH = MT * 2;            // A fragments per half K-step (packing unit)
   constexpr bool DEFER = (MB == 1);      // defer a step's last sub-step past the barrier (needs spare registers)
-  static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2, "tile geometry");
+  static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 3, "tile geometry");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sB = smem;                     // 2 x BT_BYTES
@@ -141,10 +139,10 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   // hipcc cannot share address arithmetic between the unrolled tile bodies and keep it live across a whole tile.
   int lane = tid & 63, ln = lane & 31, lh = lane >> 5;
 
-  // LDS-DMA one B tile: piece idx = row*8 + physical 16-B chunk; logical chunk = phys ^ ((row>>1)&7)
-  // (LDS destination is lane-linear, so the bank swizzle is applied to the SOURCE address).
-  // Per-lane source offsets are the same for every K-step; only the scalar tile base moves.
-  unsigned pvoff[NG];
+  // LDS-DMA of one B tile: piece idx = row*8 + physical 16-B chunk; logical chunk = phys ^ ((row>>1)&7)
+  // (the LDS destination is lane-linear, so the bank swizzle is applied to the SOURCE address).
+  unsigned pvoff[NG];     // x planes: byte offset of this lane's piece inside a tile of BN contiguous rows
+  int pchunk[NG];         // logical 16-byte chunk (0..7) this lane fetches
   int swB;
   unsigned a_voff;
   auto set_lane_ids = [&]() {
@@ -159,25 +157,39 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     for (int i = 0; i < NG; ++i) {
       const int idx = i * NTHREADS + t;
       const int row = idx >> 3, pc = idx & 7;
-      pvoff[i] = row * 128 + ((pc ^ ((row >> 1) & 7)) << 4);
+      pchunk[i] = pc ^ ((row >> 1) & 7);
+      pvoff[i] = row * 128 + (pchunk[i] << 4);
     }
   };
   set_lane_ids();
   const unsigned sB_addr = (unsigned)(size_t)WG_LPTR(sB);
-  const int R = a.g.R;
-  const int nK = 3 * CC + a.ns_chunks;
-  auto kstep_src = [&](int r0, int ks) -> const char* {      // scalar: B-tile source of K-step ks
-    if (ks < 3 * CC) {
-      const int tap = ks / CC, cc = ks - tap * CC;
-      const int row = r0 + (tap - 1) * a.dil;     // taps t-d, t, t+d (model.py:98-102: padding = dilation)
-      return (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
-    }
-    return (const char*)(a.spect + ((size_t)(ks - 3 * CC) * R + r0) * 64);
+  const int R = a.g.R, Rp = a.g.Rp, Fp = a.g.Fp, M = a.M;
+  const int nK = NKX + a.n_cond_steps;
+  const int mel_rows_per_utt = a.g.T + 6;
+
+  // Tile = (phase p, BN consecutive rows of that phase's block).  Row of column n: kRowPad + p*Rp + jt*BN + n.
+  // B-tile source of tap K-step ks (scalar): tap offset delta = (tap-1)*dil group-timesteps moves phase p to
+  // (p+delta)&31 and the frame by (p+delta)>>5 -- again BN contiguous rows (model.py:98-102: padding = dilation).
+  auto xstep_src = [&](int p, int jt, int ks) -> const char* {
+    const int tap = ks / CC, cc = ks - tap * CC;
+    const int pp = p + (tap - 1) * a.dil;
+    const int row = kRowPad + (pp & 31) * Rp + jt * BN + (pp >> 5);
+    return (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
   };
-  auto stage_B_piece = [&](int r0, int ks, int bufsel, int i) {
+  // Conditioning K-step s (folded cond_layer o upsample, K = 4 taps x M mel channels): column n needs the mel
+  // frames q-j, j = 0..3; k index = j*M + i.  Per-lane gather from the frame-major mel (mrow = melT row of the
+  // column's frame; 3 for columns outside any utterance: melT rows 0..3 are zero and mrow - j stays in bounds).
+  int mrow[NG];
+  auto cond_voff = [&](int s, int i) -> unsigned {
+    const int k0 = s * 64 + pchunk[i] * 8;
+    const int j = (k0 >= M) + (k0 >= 2 * M) + (k0 >= 3 * M);
+    return (unsigned)(((mrow[i] - j) * M + (k0 - j * M)) * 2);
+  };
+  auto stage_B_piece = [&](int p, int jt, int ks, int bufsel, int i) {
 #ifndef WG_DBG_NO_DMA
-    glds16(kstep_src(r0, ks), pvoff[i],
-           __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16));
+    const unsigned lds = __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16);
+    if (ks < NKX) glds16(xstep_src(p, jt, ks), pvoff[i], lds);
+    else glds16(a.melT, cond_voff(ks - NKX, i), lds);
 #endif
   };
   auto read_B = [&](const char* buf, int nt, int k16) -> half8 {
@@ -188,80 +200,86 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int c = (k16 * 2 + lh) ^ swB;
     return *(const half8*)(buf + n * 128 + c * 16);
   };
-  // A fragments: packed [2*nK half K-steps][wave][MT][2 k16][64 lanes][8].  q[g][mt] holds the fragment of
-  // k16 sub-step g (0..3) of the current K-step; one fragment = one 1 KiB wave-load straight from L2.
+  // A fragments, packed [half K-step][wave][MT][2 k16][64 lanes][8]: tap steps from wA1, conditioning steps from
+  // this tile's phase block of wA1c.  q[g][mt] holds the fragment of k16 sub-step g (0..3) of the current K-step;
+  // one fragment = one 1 KiB wave-load straight from L2.
+  const char* wA1c_p = nullptr;   // set per tile
   auto load_Aq = [&](int ks, int g, int mt, half8& dst) {
-#ifdef WG_DBG_A_SAME   // timing experiment only: every step re-reads fragment block 0 (L1-resident)
-    ks = 0;
-#endif
-    const char* p = (const char*)a.wA1 + ((size_t)(2 * ks + (g >> 1)) * NW + wave) * (NAH * 1024) +
-                    (mt * 2 + (g & 1)) * 1024;                                      // wave-uniform
+    const char* base = ks < NKX ? (const char*)a.wA1 : wA1c_p;
+    const int kl = ks < NKX ? ks : ks - NKX;
+    const char* p = base + ((size_t)(2 * kl + (g >> 1)) * NW + wave) * (NAH * 1024) + (mt * 2 + (g & 1)) * 1024;
 #ifndef WG_DBG_NO_ALOAD
     gload16<0>(dst, p, a_voff);
 #else
     asm volatile("" : "=v"(dst));
 #endif
   };
-  auto tile_row0 = [&](int tile) -> int {
-    const int b = tile / a.tiles_per_utt;
-    return b * a.g.Lp + a.g.G + (tile - b * a.tiles_per_utt) * BN;
+  // column -> (utterance, frame): rr = row inside the phase block
+  auto column_of = [&](int rr, int p, int& b, int& t) -> bool {
+    b = rr / Fp;
+    const int fq = rr - b * Fp - a.g.Gf;
+    t = fq * 32 + p;
+    return b < a.g.B && fq >= 0 && fq < a.g.F && t < a.g.L;
   };
 
   // ---- tile walk.  Blocks b and b+8 share an XCD (round-robin dispatch; speed only), so XCD label x owns a
-  // contiguous run of time tiles; its blocks take tiles start+idx, start+idx+step, ... (step = blocks on that
-  // label): tiles that run at the same time are neighbours and re-read each other's +-dil halo rows from that L2.
-  // A workgroup processes kTilesPerWG tiles in a FULLY UNROLLED loop: the next tile's first B tile (LDS-DMA) and A
-  // fragments are issued under the current tile's gate / GEMM2 / epilogue, and the workgroup launch cost is paid
-  // once per kTilesPerWG tiles.  (A real persistent loop makes hipcc spill 100+ VGPRs around the back edge.)
+  // contiguous run of tiles (= a few phases: their folded conditioning weights stay in that XCD's L2); its blocks
+  // take tiles start+idx, start+idx+step, ... so tiles that run at the same time are neighbours.
+  // A workgroup processes kTilesPerWG tiles in a FULLY UNROLLED loop: the next tile's first B tile (LDS-DMA) is
+  // issued under the current tile's gate / GEMM2 / epilogue, and the workgroup launch cost is paid once per
+  // kTilesPerWG tiles.  (A real persistent loop makes hipcc spill 100+ VGPRs around the back edge.)
   int tile, tile_end;
   const int tile_step = gridDim.x >> 3;        // grid is a multiple of 8
   {
     const int bid = blockIdx.x, ntl = a.n_tiles;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int q = ntl >> 3, r = ntl & 7;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    tile_end = start + (xcd < r ? q + 1 : q);
+    const int qq = ntl >> 3, r = ntl & 7;
+    const int start = xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq;
+    tile_end = start + (xcd < r ? qq + 1 : qq);
     tile = start + idx;
   }
 
-  // bias of GEMM1 (pre-scaled in_layer bias + cond bias slice), fp32 [2C], kept in LDS for the whole launch
+  // bias of GEMM1 (pre-scaled: in_layer bias + cond_layer bias slice + W_cond . upsample bias), fp32 [2C], in LDS
   float* const sBias = (float*)(sActs + BN * ACT_ROW);
   for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
 
   half8 q[4][MT];
-  half8 breg[NG];                            // register-staged B tile (kRegStageB)
   int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
   if (tile < tile_end) {
+    const int p0 = tile / a.tiles_per_phase;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(tile), 0, 0, i);
+    for (int i = 0; i < NG; ++i) stage_B_piece(p0, tile - p0 * a.tiles_per_phase, 0, 0, i);
   }
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
   __syncthreads();
 
 #pragma unroll
   for (int it = 0; it < kTilesPerWG; ++it, tile += tile_step) {
     if (tile >= tile_end) break;
-    if (it > 0) {
-      set_lane_ids();
-      if constexpr (!kXTileDMA) {
+    if (it > 0) set_lane_ids();
+    const int p = tile / a.tiles_per_phase;           // phase of every column of this tile
+    const int jt = tile - p * a.tiles_per_phase;
+    const int rr0 = jt * BN;                          // first row inside the phase block
+    const int r0 = kRowPad + p * Rp + rr0;            // first plane row of this tile
+    const int next_tile = tile + tile_step;
+    wA1c_p = (const char*)a.wA1c + (size_t)p * (2 * a.n_cond_steps) * NW * (NAH * 1024);
+    if constexpr (!kXTileDMA) {
+      if (it > 0) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(tile), 0, par, i);
-      }
-      if constexpr (!kXTileA) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+        for (int i = 0; i < NG; ++i) stage_B_piece(p, jt, 0, par, i);
       }
     }
-    const int b = tile / a.tiles_per_utt;
-    const int jt = tile - b * a.tiles_per_utt;
-    const int r0 = b * a.g.Lp + a.g.G + jt * BN;   // first plane row of this tile
-    const int t0 = jt * BN;                        // first group-timestep
-    const int next_tile = tile + tile_step;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+    // mel rows of the frames this lane gathers for the conditioning K-steps
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      int b, t;
+      const int rr = rr0 + ((i * NTHREADS + tid) >> 3);
+      const bool ok = column_of(rr, p, b, t);
+      mrow[i] = ok ? 3 + b * mel_rows_per_utt + 3 + (t >> 5) : 3;   // 3: rows 0..3 are zero, and mrow - j >= 0
+    }
     WG_STAMP(0);
     // ---- GEMM1 accumulators start from the bias
     f32x16 acc[MT][NT];
@@ -292,11 +310,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     //   g=2  slots: read bf[1] <- sub-step 3 ; reload q[1] <- A(ks+1, 1)       (wait q[2] first)
     //   then reload q[2] <- A(ks+1, 2); vmcnt(2*MT): DMA and q[0] landed; lgkmcnt(0); ONE s_barrier.
     // VMEM issue order per step: DMA xNG, q3 xMT, q0 xMT, q1 xMT, q2 xMT -- every wait is a counted vmcnt.
-    if constexpr (kRegStageB) {
-      const char* src1 = kstep_src(r0, 1);
-#pragma unroll
-      for (int i = 0; i < NG; ++i) gload16<0>(breg[i], src1, pvoff[i]);
-    }
+    // The first and last steps are peeled and "next step is a conditioning step" is a compile-time flag, so the
+    // loop bodies are branch-free.
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -309,73 +324,54 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       for (int mt = 0; mt < MT; ++mt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[g][mt], bf[g & 1][nt], acc[mt][nt], 0, 0, 0);
     };
-    if constexpr (kPersistent) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)        // bf[1] carries nothing into a tile (the ks > 0 test below): tell
-        asm volatile("" : "=v"(bf[1][nt]));  // the register allocator, or it keeps stale fragments alive
-    }
-    // One K-step; MORE = "a next step exists" is a compile-time flag (the last step is peeled) so the body has
-    // no branches (so are the first step's missing deferred MFMAs), and the next tile's DMA source is computed
-    // once per step in scalar registers.
-    auto kstep = [&](auto more_tag, auto more2_tag, auto first_tag, auto hi_tag, int ks) {
-      constexpr bool more = decltype(more_tag)::value;      // step ks+1 exists
-      constexpr bool more2 = decltype(more2_tag)::value;    // step ks+2 exists
+    // more: step ks+1 exists; ncond: step ks+1 is a conditioning step; first: no deferred MFMAs pending
+    auto kstep = [&](auto more_tag, auto ncond_tag, auto first_tag, int ks) {
+      constexpr bool more = decltype(more_tag)::value;
+      constexpr bool ncond = decltype(ncond_tag)::value;
       constexpr bool first = decltype(first_tag)::value;
-      // Stagger: the two waves of a SIMD (w, w + NW/2) run this loop in lockstep; the upper half takes its
-      // VMEM slots half a sub-step later, so one wave's load issue sits beside its partner's MFMAs.
-      constexpr int SH = decltype(hi_tag)::value ? NT / 2 : 0;
-      // VMEM ops this step issues for the B operand ahead of the q loads: LDS-DMA pieces of tile ks+1, or
-      // (register staging) the loads of tile ks+2
-      constexpr int NB = kRegStageB ? (more2 ? NG : 0) : (more ? NG : 0);
       const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
       const char* src_next = nullptr;
-      if constexpr (kRegStageB) { if constexpr (more2) src_next = kstep_src(r0, ks + 2); }
-      else { if constexpr (more) src_next = kstep_src(r0, ks + 1); }
+      if constexpr (more && !ncond) src_next = xstep_src(p, jt, ks + 1);
       const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
-      if constexpr (kRegStageB && more) {
-        // tile ks+1 (loaded during step ks-1, landed before the barrier) -> its LDS buffer, free since the barrier
-        char* wp = sB + ((ks + 1 + par) & 1) * BT_BYTES + tid * 16;
-#pragma unroll
-        for (int i = 0; i < NG; ++i) *(half8*)(wp + i * NTHREADS * 16) = breg[i];
-      }
       __builtin_amdgcn_sched_barrier(0);
       auto dma_slot = [&](int nt) {
+        if constexpr (more) {
 #pragma unroll
-        for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) {
-          if constexpr (kRegStageB) {
-            if constexpr (more2) gload16<0>(breg[i], src_next, pvoff[i]);
-          } else {
-            if constexpr (more) glds16(src_next, pvoff[i], __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16));
+          for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) {
+#ifndef WG_DBG_NO_DMA
+            const unsigned lds = __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16);
+            if constexpr (ncond) glds16(a.melT, cond_voff(ks + 1 - NKX, i), lds);
+            else glds16(src_next, pvoff[i], lds);
+#endif
           }
         }
       };
       if constexpr (DEFER) {
-        // ---- D: deferred sub-step 3 of step ks-1 + B-operand loads
+        // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           if constexpr (!first) mfma_col(3, nt);
           __builtin_amdgcn_sched_barrier(0);
-          dma_slot((nt + NT - SH) % NT);
+          dma_slot(nt);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
       for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
-        if (g == 1) wait_vm<2 * MT + NB>();                          // q[1] landed
-        if (g == 2) wait_vm<NB + MT + (more ? MT : 0)>();            // q[2] landed
-        if (g == 3) wait_vm<more ? 2 * MT : 0>();                    // q[3] landed (no deferral)
+        if (g == 1) wait_vm<more ? 2 * MT + NG : 2 * MT>();      // q[1] landed
+        if (g == 2) wait_vm<more ? NG + 2 * MT : MT>();          // q[2] landed
+        if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           mfma_col(g, nt);
           __builtin_amdgcn_sched_barrier(0);
           if (g < 3) bf[(g + 1) & 1][nt] = read_B(buf, nt, g + 1);
-          const int snt = (nt + NT - SH) % NT;
-          if (!DEFER && g == 0) dma_slot(snt);
+          if (!DEFER && g == 0) dma_slot(nt);
           if (g == 0 || more) {
 #pragma unroll
-            for (int mt = snt * LPS; mt < (snt + 1) * LPS && mt < MT; ++mt)
+            for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
               load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -386,29 +382,24 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 1, 2, mt, q[2][mt]);
         }
-        // B operand of the next steps and q[0] landed (only q[1], q[2] reloads may be outstanding); own LDS
-        // reads of this buffer and LDS writes of the next one done
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * MT) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * MT) : "memory");   // DMA, q[0] landed; reads done
 #ifndef WG_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto kloop = [&](auto hi_tag) {
-      using T = std::true_type;
-      using F = std::false_type;
-      kstep(T{}, T{}, T{}, hi_tag, 0);            // nK >= 13: first, middle, second-last and last steps all exist
+    {
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      kstep(T_{}, F_{}, T_{}, 0);                                   // tap steps 0 .. NKX-2: next is a tap step
 #pragma clang loop unroll(disable)
-      for (int ks = 1; ks < nK - 2; ++ks) kstep(T{}, T{}, F{}, hi_tag, ks);
-      kstep(T{}, F{}, F{}, hi_tag, nK - 2);
-      kstep(F{}, F{}, F{}, hi_tag, nK - 1);
-    };
-#ifdef WG_STAGGER   // experiment: two copies of the loop push hipcc into spilling (26 VGPRs @C=256) -- off
-    if (wave >= NW / 2) kloop(std::true_type{}); else kloop(std::false_type{});
-#else
-    kloop(std::false_type{});
-#endif
+      for (int ks = 1; ks < NKX - 1; ++ks) kstep(T_{}, F_{}, F_{}, ks);
+      kstep(T_{}, T_{}, F_{}, NKX - 1);                             // last tap step: next is conditioning
+#pragma clang loop unroll(disable)
+      for (int ks = NKX; ks < nK - 1; ++ks) kstep(T_{}, T_{}, F_{}, ks);
+      kstep(F_{}, F_{}, F_{}, nK - 1);                              // last conditioning step
+    }
     if constexpr (DEFER) {
       wait_vm<0>();                          // q[3] of the last step
 #pragma unroll
@@ -417,18 +408,19 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     par = (par + nK) & 1;
     // Next tile's first B tile goes out now, into the LDS buffer the last step did not use (slow waves may
-    // still be reading that one); its A fragments follow after the gate -- all land under the phases below.
+    // still be reading that one) -- it lands under the phases below.
     if constexpr (kXTileDMA) {
       if (next_tile < tile_end) {
+        const int pn = next_tile / a.tiles_per_phase;
 #pragma unroll
-        for (int i = 0; i < NG; ++i) stage_B_piece(tile_row0(next_tile), 0, par, i);
+        for (int i = 0; i < NG; ++i) stage_B_piece(pn, next_tile - pn * a.tiles_per_phase, 0, par, i);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 
     WG_STAMP(2);
     // Per-tile opaque copies of the lane ids: every address / weight load of the phases below depends on them,
-    // so hipcc cannot hoist those (tile-invariant) values out of the persistent loop and spill them around it
+    // so hipcc cannot hoist those (tile-invariant) values out of the tile bodies and spill them
     // (a spill reload is a VMEM op whose compiler-inserted vmcnt(0) would drain the hand-placed prefetches).
     int lno = ln, lho = lh, laneo = lane;
     asm volatile("" : "+v"(lno), "+v"(lho), "+v"(laneo));
@@ -458,7 +450,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- gate (model.py:13-20) in registers; acts -> LDS as fp16, position-major, XOR-swizzled
+    // ---- gate (model.py:13-20) in registers; acts -> LDS as fp16, position-major, padded rows
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -477,15 +469,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     WG_STAMP(3);
-    // The accumulators are dead now: room for the next tile's first A fragments.  Unconditional (the weights
-    // are the same for every tile) so h0/h1 are plainly dead across the gate above, not "maybe still needed".
-    if constexpr (kXTileA) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
 
     // GEMM2 accumulators start from x + b_res (residual add for free, model.py:132)
     f32x16 acc2[MB][NT];
@@ -510,6 +493,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       return *(const half8*)(acts_rd + nt * 32 * ACT_ROW + k16 * 32);
     };
 
+    // ---- folded end x skip, part 1: issue the weight-fragment loads now, consume after GEMM2
     const int l15 = laneo & 15, l4 = laneo >> 4;
     constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
     constexpr bool kWesEarly = (C / 32) * 4 <= 32;           // folded-end weight fragments fit beside GEMM2's registers
@@ -552,9 +536,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       const int grp = wave + gi * NW;
       if (grp < BN / 16) {
         const int n = grp * 16 + l15;
-        const int t = t0 + n;
-        const bool valid = laneo < 32 && t < a.g.L;
-        float4* op = (float4*)(a.out + ((size_t)b * a.g.L + t) * 8 + 4 * l4);
+        int cb, ct;
+        const bool valid = column_of(rr0 + n, p, cb, ct) && laneo < 32;
+        float4* op = (float4*)(a.out + ((size_t)cb * a.g.L + ct) * 8 + 4 * l4);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) o = *op;
         const char* ep = sActs + n * ACT_ROW + l4 * 16;
@@ -575,14 +559,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     }
 
     WG_STAMP(5);
-    // ---- x_out = fp16(x + res) for valid columns (rows >= L stay zero: they are other tiles' padding)
+    // ---- x_out = fp16(x + res) for valid columns (all other rows stay zero: they are the padding of other tiles)
     if constexpr (HAS_RES) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int blk = wave * MB + mb;
+      for (int nt = 0; nt < NT; ++nt) {
+        int cb, ct;
+        if (column_of(rr0 + nt * 32 + lno, p, cb, ct)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (t0 + nt * 32 + lno < a.g.L) {
+          for (int mb = 0; mb < MB; ++mb) {
+            const int blk = wave * MB + mb;
             half8 o0, o1;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -660,97 +645,103 @@ hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s) {
 }
 
 // =============================================================================================
-// Upsample: ConvTranspose1d(M, M, 1024, stride 256) (model.py:145-150) written straight into the squeezed
-// conditioning planes (model.py:230-232), as an MFMA GEMM per frame phase t' (= group-timestep inside a frame):
-//   S[ch = o*8+g][frame q] = bias[o] + sum_{j<4, i<M} W[i][o][8t'+g+256j] * mel[i][q-j]
-// i.e. [NS x 4M] . [4M x frames].  One workgroup: one t', 128 consecutive frames of one utterance, all NS
-// channels; 5 waves, wave w owns the 64-channel plane chunks w, w+5, ...  The mel window is transposed once
-// into LDS as fp16 [frame][i] (row stride M+8 halfs => conflict-free ds_read_b128 B fragments); weights come
-// pre-packed in A-fragment order straight from L2.  Output lanes hold 16 consecutive storage positions of one
-// row => two 16-byte stores (spect planes use the same position-major channel order as x, wg_common.h).
+// Conditioning input.  The reference upsamples the mel with ConvTranspose1d(M, M, 1024, stride 256)
+// (model.py:145-150, :225-232) and feeds the squeezed result to every WN's cond_layer (model.py:121).  Both are
+// linear, so per phase p (group-timestep inside a frame) they compose into ONE matrix acting on the 4 mel frames
+// q..q-3:   cond[m][t = 32q+p] = sum_{j<4, i<M} Wc_p[m][j*M+i] * mel[i][q-j] + const,
+//           Wc_p[m][j*M+i] = sum_{o<M, g<8} W_cond[m][o*8+g] * W_up[i][o][8p+g+256j]
+// -- K = 4M = 320 instead of 8M = 640 per cond slice, and the upsampled [B,640,L] tensor never exists.
+// mel_pack_kernel transposes the mel to frame-major fp16 rows (the B operand of those K-steps);
+// cond_fold_kernel builds Wc_p for every (layer, phase) in MFMA A-fragment order at weight-load time.
 // =============================================================================================
-constexpr int UP_FRAMES = 128;
-constexpr int UP_WAVES = 5;
-
-__global__ void __launch_bounds__(UP_WAVES * 64) upsample_kernel(const UpsampleArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int M = a.M;
-  const int RS = (M + 8) * 2;                 // melT row stride in bytes
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ln = lane & 31, lh = lane >> 5;
-  const int tp = blockIdx.x;                  // t'
-  const int q0 = blockIdx.y * UP_FRAMES;
-  const int b = blockIdx.z;
-  const int NF = UP_FRAMES + 3;               // frames q0-3 .. q0+127
-  for (int idx = tid; idx < M * NF; idx += UP_WAVES * 64) {
-    const int i = idx / NF, f = idx - i * NF;
-    const int q = q0 - 3 + f;
-    const float v = (q >= 0 && q < a.T) ? load_io(a.mel, ((size_t)b * M + i) * a.T + q, a.io_f16) : 0.0f;
-    *(_Float16*)(smem + f * RS + i * 2) = (_Float16)v;
-  }
-  __syncthreads();
-  const int KS = M / 4;                       // k16 steps (K = 4M)
-  const int KPJ = M / 16;                     // k16 steps per tap
-  const int NSC = M / 8;                      // 64-channel chunks (NS/64)
-  const half8* const wp = (const half8*)a.w;  // [32 t'][NSC][2 mb][KS][64 lanes][8]
-  for (int cs = wave; cs < NSC; cs += UP_WAVES) {
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      f32x16 v;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = cs * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        v[r] = a.bias[ch >> 3];
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mb][nt] = v;
+__global__ void __launch_bounds__(256) mel_pack_kernel(const MelPackArgs a) {
+  // rows: 3 zero | per utterance: 3 zero, T frames, 3 zero
+  const int rows_per_utt = a.T + 6;
+  const size_t n = (size_t)(3 + a.B * rows_per_utt) * a.M;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+    const int i = (int)(idx % a.M);
+    const int row = (int)(idx / a.M) - 3;
+    float v = 0.0f;
+    if (row >= 0) {
+      const int b = row / rows_per_utt, f = row - b * rows_per_utt - 3;
+      if (f >= 0 && f < a.T) v = load_io(a.mel, ((size_t)b * a.M + i) * a.T + f, a.io_f16);
     }
-    const half8* pa = wp + ((size_t)(tp * NSC + cs) * 2 * KS) * 64 + lane;
-    for (int k = 0; k < KS; ++k) {
-      const int j = k / KPJ, i0 = (k - j * KPJ) * 16;
-      const half8 a0 = pa[(size_t)k * 64];
-      const half8 a1 = pa[(size_t)(KS + k) * 64];
-      half8 bf[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        bf[nt] = *(const half8*)(smem + (nt * 32 + ln + 3 - j) * RS + (i0 + 8 * lh) * 2);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[nt], acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[nt], acc[1][nt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int q = q0 + nt * 32 + ln;
-      const int t = q * 32 + tp;
-      if (t < a.g.L) {
-        const size_t row = (size_t)b * a.g.Lp + a.g.G + t;
-        _Float16* dst = a.spect + ((size_t)cs * a.g.R + row) * 64 + lh * 16;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          half8 o0, o1;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            o0[r] = (_Float16)acc[mb][nt][r];
-            o1[r] = (_Float16)acc[mb][nt][8 + r];
-          }
-          *(half8*)(dst + mb * 32) = o0;
-          *(half8*)(dst + mb * 32 + 8) = o1;
-        }
-      }
-    }
+    a.melT[idx] = (_Float16)v;
   }
 }
 
-hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s) {
-  if (a.M % 16 != 0 || a.M > 80) return hipErrorInvalidValue;
-  dim3 grid(32, (a.n_q + UP_FRAMES - 1) / UP_FRAMES, a.g.B);
-  const int smem = (UP_FRAMES + 3) * (a.M + 8) * 2;
-  hipLaunchKernelGGL(upsample_kernel, grid, dim3(UP_WAVES * 64), smem, s, a);
+hipError_t launch_mel_pack(const MelPackArgs& a, hipStream_t s) {
+  const size_t n = (size_t)(3 + a.B * (a.T + 6)) * a.M;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mel_pack_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// One block: one (layer l, phase p, tap j) and 64 gate rows m; computes the [64 x M] block
+//   Wc[m][i] = sum_{s = o*8+g} W_cond[2C*l + m][s] * W_up[i][o][8p + g + 256 j]
+// in fp32 through LDS tiles and scatters it, gate pre-scaled and rounded to fp16, into A-fragment order
+// [l][p][half K-step][wave][MT][2 k16][64 lanes][8]   (K index kk = j*M + i; see wn_layer_kernel::load_Aq).
+__global__ void __launch_bounds__(256) cond_fold_kernel(const float* __restrict__ w_cond, const float* __restrict__ w_up,
+                                                        _Float16* __restrict__ out, int C, int NW, int M, int up_kernel,
+                                                        float tanh_scale, float sigm_scale) {
+  __shared__ float sW[64][33];    // W_cond rows m0..m0+63, s-chunk of 32
+  __shared__ float sU[32][81];    // U[s][i] = W_up[i][o][8p+g+256j]
+  const int p = blockIdx.x >> 2, j = blockIdx.x & 3;
+  const int m0 = blockIdx.y * 64;
+  const int l = blockIdx.z;
+  const int NS = M * 8, MB = C / (32 * NW), MT = 2 * MB;
+  const int tid = threadIdx.x;
+  float acc[20];                                   // 64 x 80 outputs / 256 threads (M <= 80)
+#pragma unroll
+  for (int e = 0; e < 20; ++e) acc[e] = 0.0f;
+  const int per_thread = (64 * M + 255) / 256;
+  for (int s0 = 0; s0 < NS; s0 += 32) {
+    for (int e = tid; e < 64 * 32; e += 256) {
+      const int mm = e >> 5, ss = e & 31;
+      sW[mm][ss] = w_cond[((size_t)(2 * C * l + m0 + mm)) * NS + s0 + ss];
+    }
+    for (int e = tid; e < 32 * M; e += 256) {
+      const int ss = e / M, i = e - ss * M;
+      const int sch = s0 + ss, o = sch >> 3, g = sch & 7;
+      sU[ss][i] = w_up[((size_t)i * M + o) * up_kernel + 8 * p + g + 256 * j];
+    }
+    __syncthreads();
+    for (int e = 0; e < per_thread; ++e) {
+      const int idx = e * 256 + tid;
+      if (idx < 64 * M) {
+        const int mm = idx / M, i = idx - mm * M;
+        float v = acc[e];
+#pragma unroll 8
+        for (int ss = 0; ss < 32; ++ss) v = fmaf(sW[mm][ss], sU[ss][i], v);
+        acc[e] = v;
+      }
+    }
+    __syncthreads();
+  }
+  const int n_half = 2 * (M / 16);                 // half K-steps of the conditioning part
+  for (int e = 0; e < per_thread; ++e) {
+    const int idx = e * 256 + tid;
+    if (idx >= 64 * M) continue;
+    const int mm = idx / M, i = idx - mm * M;
+    const int m = m0 + mm;                         // gate row in [0, 2C)
+    const bool tanh_row = m < C;
+    const int ch = tanh_row ? m : m - C;           // gate channel
+    const int blk = ch >> 5, r = ch & 31;
+    const int w = blk / MB, mt = (tanh_row ? 0 : MB) + (blk - w * MB);
+    const int kk = j * M + i;
+    const int u = kk >> 5, k2 = (kk >> 4) & 1, hh = (kk >> 3) & 1, jj = kk & 7;
+    const size_t frag = ((((size_t)(l * kPhases + p) * n_half + u) * NW + w) * MT + mt) * 2 + k2;
+    out[(frag * 64 + hh * 32 + r) * 8 + jj] = (_Float16)(acc[e] * (tanh_row ? tanh_scale : sigm_scale));
+  }
+}
+
+hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* out, int C, int NW, int M, int n_layers,
+                            int up_kernel, float tanh_scale, float sigm_scale, hipStream_t s) {
+  if (M > 80 || M % 16) return hipErrorInvalidValue;
+  dim3 grid(kPhases * 4, 2 * C / 64, n_layers);
+  hipLaunchKernelGGL(cond_fold_kernel, grid, dim3(256), 0, s, w_cond, w_up, out, C, NW, M, up_kernel, tanh_scale,
+                     sigm_scale);
   return hipGetLastError();
 }
 
@@ -918,7 +909,8 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
       for (int e = 0; e < 8; ++e)
         o[e] = (_Float16)fmaf(w[e][3], a0.w, fmaf(w[e][2], a0.z, fmaf(w[e][1], a0.y, fmaf(w[e][0], a0.x, bs[e]))));
       const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
-      const size_t prow = (size_t)b * a.g.Lp + a.g.G + t;
+      // phase-major plane row of (b, t = 32q + p), see RowGeom
+      const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
       *(half8*)(a.x + ((size_t)cc * a.g.R + prow) * 64 + g8 * 8) = o;
     }
   }

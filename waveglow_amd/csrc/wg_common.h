@@ -30,22 +30,35 @@ __host__ __device__ inline int chan_to_pos(int c) {
 constexpr int kMaxGroup = 8;     // n_group (flow state channels)
 constexpr int kBK = 64;          // GEMM K-step (fp16 elements) = one 128-byte row of a chunk plane
 
-// Row geometry of the time-major activation planes.  Every utterance owns Lp rows:
-// G zero guard rows | Ltile rows (L valid, rest never written => zero) | G zero guard rows.
+// Row geometry of the activation planes x: [C/64 chunks][rows][64 channels], rows in PHASE-MAJOR time order.
+// A group-timestep t = 32*q + p (q = mel frame, p = phase inside the frame, 32 = upsample_stride / n_group) of
+// utterance b lives in row  p*Rp + b*Fp + Gf + q:  every phase owns a block of Rp rows; inside it every
+// utterance owns Fp = Gf + F + Gf rows (F = ceil(L/32) frames, Gf zero guard frames each side).  With this order
+//   * a dilated tap t +- d of a run of consecutive frames of ONE phase is again a run of consecutive rows (of
+//     phase (p +- d) & 31, shifted by (p +- d) >> 5 frames): every GEMM B tile stays BN contiguous 128-byte rows;
+//   * all columns of a tile share the phase, so the cond_layer o upsample fold (one weight matrix per phase,
+//     api.cpp) applies to the whole tile.
+// Guard rows are never written and read as the convolution's zero padding (model.py:98-102).
 struct RowGeom {
   int B;        // utterances
   int L;        // valid group-timesteps per utterance
-  int Ltile;    // L rounded up to 128
-  int G;        // guard rows each side (>= max dilation)
-  int Lp;       // G + Ltile + G
-  int R;        // B * Lp
+  int F;        // frames per utterance = ceil(L / 32)
+  int Gf;       // guard frames each side (>= max dilation / 32)
+  int Fp;       // Gf + F + Gf
+  int Rp;       // rows per phase block = B * Fp rounded up to 128
+  int R;        // 32 * Rp + 2 * kRowPad  (plane rows incl. slack before row 0 and after the last row)
+  int T;        // mel frames of the input (melT rows per utterance = 3 + T + 3)
 };
+constexpr int kRowPad = 8;       // zero slack rows in front of / behind every plane chunk (taps of the first/last tile)
+constexpr int kPhases = 32;
 
 struct WnLayerArgs {
   const _Float16* x_in;     // [C/64][R][64] position-major
   _Float16* x_out;          // same layout (ping-pong), unused when !has_res
-  const _Float16* spect;    // [NS/64][R][64] position-major
-  const _Float16* wA1;      // packed GEMM1 A fragments  [2nK half-steps][NW][MT][2][64][8]
+  const _Float16* melT;     // [3 + B*(3+T+3)][M] fp16 frame-major mel (3 zero rows of slack, then per utterance
+                            // 3 zero rows, T frames, 3 zero rows)
+  const _Float16* wA1;      // packed GEMM1 A fragments of the 3 taps  [2*3C/64 half-steps][NW][MT][2][64][8]
+  const _Float16* wA1c;     // ... of the folded cond_layer o upsample, per phase  [32][2*M/16 half-steps][NW][MT][2][64][8]
   const float* bias1;       // [2C]  b_in + b_cond slice
   const _Float16* wA2;      // packed GEMM2 A fragments  [NW][MB][C/16][64][8]
   const float* bias2;       // [C]   b_res
@@ -53,22 +66,19 @@ struct WnLayerArgs {
   float* out;               // [B*L][8] fp32, accumulated across layers
   RowGeom g;
   int dil;                  // dilation of this layer
-  int ns_chunks;            // NS/64 (spect K-steps)
+  int n_cond_steps;         // K-steps of the folded conditioning = 4*M/64 = M/16
+  int M;                    // n_mel_channels
   int has_res;              // 0 for the last layer of a WN (model.py:106-110)
-  int tiles_per_utt;        // Ltile / BN
-  int n_tiles;              // B * tiles_per_utt
+  int tiles_per_phase;      // Rp / BN
+  int n_tiles;              // 32 * tiles_per_phase
   int n_cu;                 // compute units of the device (persistent grid size)
   unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
 };
 
-struct UpsampleArgs {
+struct MelPackArgs {
   const void* mel;          // [B][M][T] io dtype
-  const _Float16* w;        // packed A fragments [32 t'][NS/64][2][M/4][64][8]
-  const float* bias;        // [M]
-  _Float16* spect;          // [NS/64][R][64]
-  RowGeom g;
-  int M, T, io_f16;
-  int n_q;                  // number of output frames q covering 8*L samples: ceil(8L/256)
+  _Float16* melT;           // see WnLayerArgs::melT
+  int B, M, T, io_f16;
 };
 
 struct FlowArgs {
@@ -106,7 +116,10 @@ struct FlowArgs {
 };
 
 // launch wrappers (kernels.hip)
-hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
+hipError_t launch_mel_pack(const MelPackArgs& a, hipStream_t s);
+// derived weights: A fragments of (W_cond slice of layer l) x (upsample taps of phase p), see api.cpp
+hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* out, int C, int NW, int M, int n_layers,
+                            int up_kernel, float tanh_scale, float sigm_scale, hipStream_t s);
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
 hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // bn = 128 (default) or 64
 int wn_block_n(int C);   // default BN for channel count C
