@@ -82,14 +82,16 @@ def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
     return time.perf_counter() - t0
 
   run(10)                        # warm-up (thread pool, oneDNN primitive caches)
-  t_probe = run(40)              # probe; run time grows faster than linearly in T (cache footprint), so aim low
-  T = int(max(40, min(500, 40 * 6.0 / max(t_probe, 1e-3))))
-  if T <= 48:
-    T, best = 40, t_probe
-  else:
-    best = run(T)
-    if best < seconds_hint / 3:
-      best = min(best, run(T))
+  # Run time grows faster than linearly in T on some hosts (the [4096, 32T] cond tensor falls out of cache), so
+  # double T while the last run stayed short and the next one is predicted to fit the budget.
+  T, best, spent = 32, None, 0.0
+  while True:
+    dt = run(T)
+    spent += dt
+    best = dt
+    if T >= 500 or dt * 3.0 + spent > seconds_hint:
+      break
+    T = min(500, T * 2)
   return {"value": round(256 * T / best, 1), "unit": "samples/s", "cores": cores, "kind": "port",
           "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}] (configs[0] is T=500), sigma 0.6, {best:.2f} s"}
 

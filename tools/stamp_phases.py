@@ -37,7 +37,7 @@ with torch.no_grad():
   m.infer(mel, 0.6)
   eng = m._engine
   BN = 64 if C >= 512 else 128
-  n_tiles = B * ((32 * T + 127) // 128 * 128) // BN
+  n_tiles = 32 * ((B * (T + 8) + 127) // 128 * 128) // BN   # 32 phases x (rows per phase block / BN), see RowGeom
   buf = torch.zeros(n_tiles * 8, dtype=torch.int64, device="cuda")
   eng.lib.wg_debug_set_stamp_buffer(eng.handle, buf.data_ptr())
   m.infer(mel, 0.6)
