@@ -192,7 +192,7 @@ def main():
                    "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4),
                    "traffic": pmc_traffic_bytes(args), "avg_launch_ms": round(avg_wn_ms, 4), "launches_timed": n_wn,
                    "algorithmic_flops_per_launch": flops_per_launch,
-                   "kernel_ms_per_step": {"upsample": round(ms[0] / args.steps, 3), "flow_start": round(ms[1] / args.steps, 3),
+                   "kernel_ms_per_step": {"mel_pack": round(ms[0] / args.steps, 3), "flow_start": round(ms[1] / args.steps, 3),
                                           "wn_layer": round(ms[2] / args.steps, 3), "memset": round(ms[3] / args.steps, 3)}},
     }
     if world == 1 and not args.no_cpu_baseline:

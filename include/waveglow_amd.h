@@ -121,7 +121,7 @@ double wg_macs_per_group_step(const wg_handle* h);
 
 /* Per-kernel device timing: when enabled, wg_infer brackets its kernels with hipEvents on `stream`;
  * wg_profile_read synchronises those events and returns accumulated milliseconds per kernel class.
- * classes: 0 = upsample, 1 = flow/start, 2 = wn_layer, 3 = other. */
+ * classes: 0 = mel_pack, 1 = flow/start, 2 = wn_layer, 3 = memset. */
 int wg_profile_enable(wg_handle* h, int32_t on);
 int wg_profile_read(wg_handle* h, double* ms_per_class, int64_t* launches_per_class, int32_t n_classes);
 
