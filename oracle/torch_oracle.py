@@ -167,3 +167,23 @@ def loss_ref(z: Tensor, log_s_list: Sequence[Tensor], log_det_list: Sequence[Ten
   log_det_total = sum(log_det_list)
   loss = torch.sum(z * z) / (2 * sigma * sigma) - log_s_total - log_det_total
   return loss / (z.size(0) * z.size(1) * z.size(2))
+
+
+def grads_ref(sd_weightnorm: Dict[str, Tensor], mel: Tensor, audio: Tensor, cfg: OracleConfig, sigma: float = 1.0
+              ) -> Tuple[Tensor, Dict[str, Tensor]]:
+  """One training step's loss and parameter gradients, as the reference computes them (train.py:190-196:
+  forward -> WaveGlowLoss -> backward) on the weight-normed parameter set (686-key form): the weights are
+  re-composed with torch._weight_norm(v, g, 0) exactly like the parametrization does, then forward_ref / loss_ref
+  run under autograd.  Returns (loss, {state_dict key: gradient})."""
+  leaves = {k: v.clone().requires_grad_(True) for k, v in sd_weightnorm.items()}
+  dense: Dict[str, Tensor] = {}
+  for k, v in leaves.items():
+    if k.endswith("parametrizations.weight.original1"):
+      base = k[:-len("parametrizations.weight.original1")]
+      dense[base + "weight"] = torch._weight_norm(v, leaves[base + "parametrizations.weight.original0"], 0)
+    elif not k.endswith("parametrizations.weight.original0"):
+      dense[k] = v
+  z, log_s, log_det = forward_ref(dense, mel, audio, cfg)
+  loss = loss_ref(z, log_s, log_det, sigma)
+  grads = torch.autograd.grad(loss, list(leaves.values()))
+  return loss.detach(), dict(zip(leaves.keys(), grads))

@@ -51,3 +51,21 @@ def test_weightnorm_checkpoint_form(name):
   ref = torch.from_numpy(c.npz["audio_from_weightnorm_ckpt"])
   # reference-through-its-own-fold differs from the dense-weight run only by fold rounding
   assert float((ref - c.audio).abs().max()) < 5e-4
+
+
+def test_training_gradients_match_reference():
+  """Pins the oracle's backward (to be the checker of the training-direction kernels) against the reference's
+  own loss.backward() (tests/golden/make_golden_grads.py)."""
+  import os
+  from waveglow_amd import synthetic
+  c = Case("c64")
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c64_grads.npz"), allow_pickle=False)
+  wav = torch.from_numpy(c.npz["fwd_audio_in"])
+  loss, grads = O.grads_ref(synthetic.to_weightnorm_form(c.sd), c.mel, wav, c.oracle_cfg(), 1.0)
+  assert abs(float(loss) - float(fx["loss"])) <= 1e-7
+  assert len(grads) == sum(1 for k in fx.files if k.startswith("norm/"))
+  for name, g in grads.items():
+    assert abs(float(g.norm()) - float(fx["norm/" + name])) <= 2e-5 * max(1.0, float(fx["norm/" + name])), name
+    np.testing.assert_allclose(g.flatten()[:8].numpy(), fx["head/" + name], rtol=2e-4, atol=1e-7, err_msg=name)
+    if "full/" + name in fx.files:
+      np.testing.assert_allclose(g.numpy(), fx["full/" + name], rtol=2e-4, atol=1e-7, err_msg=name)
