@@ -84,7 +84,7 @@ constexpr bool kXTileDMA = kPersistent;
 // (The next tile's A fragments are NOT prefetched under the epilogue: between such an inline-asm load and its
 // wait lies a long stretch of compiler-scheduled code, and hipcc moved the still-in-flight destination registers
 // there -- wrong results.  They are loaded at the tile top: ~1 L2 latency exposed per tile.)
-constexpr int kTilesPerWG = 2;        // tiles per workgroup, fully unrolled
+constexpr int kTilesPerWG = 2;        // tiles per workgroup (template TPW), fully unrolled; 1 for small workloads
 // Tried and measured slower on MI355X, kept out of the source: staging B tiles global -> VGPR -> ds_write instead
 // of LDS-DMA (K loop 59.3k vs 57.6k cycles per tile); offsetting the VMEM slots of the two waves of a SIMD
 // (two copies of the loop made hipcc spill).
@@ -112,7 +112,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // Wave w owns gate channels [32*MB*w, 32*MB*(w+1)): its A (weight) fragments are private, so they go L2 -> VGPR
 // directly (pre-packed in fragment order, 1 KiB per wave-load); the B tile (activations) is shared by all waves
 // and goes HBM/L2 -> LDS by LDS-DMA.  All VMEM of the K loop is hand-counted (see glds16).
-template <int C, int NW, int BN, bool HAS_RES>
+template <int C, int NW, int BN, bool HAS_RES, int TPW>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
   constexpr int MB = C / (32 * NW);      // 32-channel blocks per wave
   constexpr int MT = 2 * MB;             // M tiles per wave: MB tanh blocks, then MB sigmoid blocks
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   __syncthreads();
 
 #pragma unroll
-  for (int it = 0; it < kTilesPerWG; ++it, tile += tile_step) {
+  for (int it = 0; it < TPW; ++it, tile += tile_step) {
     if (tile >= tile_end) break;
     if (it > 0) set_lane_ids();
     const int p = tile / a.tiles_per_phase;           // phase of every column of this tile
@@ -587,22 +587,28 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   }
 }
 
-template <int C, int BN, bool HAS_RES>
-static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
+template <int C, int BN, bool HAS_RES, int TPW>
+static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 2 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  // kTilesPerWG tiles per workgroup: per XCD label ceil(tiles_on_label / kTilesPerWG) blocks
-  const int per_label = ((a.n_tiles + 7) / 8 + kTilesPerWG - 1) / kTilesPerWG;
+  // TPW tiles per workgroup: per XCD label ceil(tiles_on_label / TPW) blocks
+  const int per_label = ((a.n_tiles + 7) / 8 + TPW - 1) / TPW;
   const int grid = 8 * per_label;
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES>), dim3(grid), dim3(NW * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
+}
+template <int C, int BN, bool HAS_RES>
+static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
+  // two tiles per workgroup amortise the launch and prefetch across the tile seam, but need >= 2 tiles per CU
+  if (a.n_tiles >= 2 * kTilesPerWG * a.n_cu) return launch_wn_ttt<C, BN, HAS_RES, kTilesPerWG>(a, s);
+  return launch_wn_ttt<C, BN, HAS_RES, 1>(a, s);
 }
 template <int C>
 static hipError_t launch_wn_t(const WnLayerArgs& a, int bn, hipStream_t s) {
