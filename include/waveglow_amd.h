@@ -125,6 +125,22 @@ double wg_macs_per_group_step(const wg_handle* h);
 int wg_profile_enable(wg_handle* h, int32_t on);
 int wg_profile_read(wg_handle* h, double* ms_per_class, int64_t* launches_per_class, int32_t n_classes);
 
+/* ---- Denoiser (src/waveglow/denoiser.py:14-57 on the conv-STFT of src/waveglow/stft.py:98-198), fp32 -----------------
+ * wg_stft_create: fwd_basis / inv_basis are the reference's windowed bases [2*513][1024] (STFT.__init__,
+ *   stft.py:108-132: real rows then imaginary rows), win_sq the squared zero-centred window [1024]; HOST pointers.
+ * wg_stft_denoise: audio [B][n_samples] fp32 device (n_samples % 256 == 0) ->
+ *   audio_out [B][n_samples] = istft(max(|X| - strength*bias_mag, 0) * exp(i*arg X))   (Denoiser.forward), and/or
+ *   mag0_out [B][513] = |X| of frame 0 (what Denoiser.__init__ keeps as bias_spec).  bias_mag null => no subtraction;
+ *   audio_out null => transform only.  Enqueue-only. */
+typedef struct wg_stft wg_stft;
+int wg_stft_create(const float* fwd_basis, const float* inv_basis, const float* win_sq, int32_t filter_length,
+                   int32_t hop_length, int32_t device_id, wg_stft** out);
+int wg_stft_destroy(wg_stft* h);
+size_t wg_stft_workspace_bytes(const wg_stft* h, int32_t B, int32_t n_samples);
+int wg_stft_denoise(wg_stft* h, const float* audio, const float* bias_mag, float strength, float* audio_out,
+                    float* mag0_out, int32_t B, int32_t n_samples, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* Diagnostic builds only (-DWG_STAMPS): device buffer of n_tiles*8 uint64 that the WN-layer kernel fills with
  * s_memtime stamps at its phase boundaries (last launch wins).  A no-op pointer in the shipped library. */
 int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer);

@@ -238,3 +238,41 @@ def test_synthesizer_and_cli_end_to_end(tmp_path):
   assert rc == 0
   rate, data = wavfile.read(out / "sub" / "a.wav")
   assert rate == 22050 and data.dtype == np.int16 and data.shape == (12 * 256,) and np.abs(data).max() == 32767
+
+
+def test_denoiser_stft_vs_numpy_oracle():
+  """The HIP denoiser (exact-fp32 MFMA conv-STFT) against oracle/stft_oracle.py (numpy fp64 restatement of
+  stft.py / denoiser.py; parity unpinned against the reference itself: its STFT module needs librosa)."""
+  import ctypes as C
+  import numpy as np
+  from oracle import stft_oracle as S
+  from waveglow_amd import _lib
+  from waveglow_amd.denoiser import stft_bases
+  lib = _lib.load()
+  fwd, inv, wsq = stft_bases()
+  h = C.c_void_p()
+  _lib.check(lib.wg_stft_create(fwd.ctypes.data, inv.ctypes.data, wsq.ctypes.data, 1024, 256, 0, C.byref(h)))
+  rng = np.random.default_rng(3)
+  for B, T in ((2, 12), (1, 88), (3, 37)):
+    x = (rng.standard_normal((B, 256 * T)) * 0.3).astype(np.float32)
+    bias = np.abs(rng.standard_normal(513)).astype(np.float32) * 5.0
+    strength = 0.1
+    ref = S.denoise(x.astype(np.float64), bias.astype(np.float64), strength, *S.bases())
+    re, im = S.transform(x.astype(np.float64), S.bases()[0])
+    mag0_ref = np.sqrt(re ** 2 + im ** 2)[:, :, 0]
+    xd, bd = torch.from_numpy(x).cuda(), torch.from_numpy(bias).cuda()
+    out = torch.empty_like(xd)
+    mag0 = torch.empty((B, 513), dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.wg_stft_workspace_bytes(h, B, 256 * T), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.wg_stft_denoise(h, xd.data_ptr(), bd.data_ptr(), strength, out.data_ptr(), mag0.data_ptr(), B, 256 * T,
+                                   ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    print(f"denoise B{B} T{T}: max err {err:.2e}  mag0 err {float(np.abs(mag0.cpu().numpy() - mag0_ref).max()):.2e}")
+    assert err <= 2e-5
+    np.testing.assert_allclose(mag0.cpu().numpy(), mag0_ref, rtol=1e-4, atol=1e-4)
+    # strength 0 / no bias -> identity (perfect reconstruction of the STFT pair)
+    _lib.check(lib.wg_stft_denoise(h, xd.data_ptr(), None, 0.0, out.data_ptr(), None, B, 256 * T, ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    assert float((out - xd).abs().max()) <= 2e-5
+  lib.wg_stft_destroy(h)

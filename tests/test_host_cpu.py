@@ -126,3 +126,23 @@ def test_synthetic_inputs_are_deterministic():
   z, ze = synthetic.make_noise(hp, 2, 160)
   assert z.shape == (2, 4, 160) and sorted(ze) == [4, 8] and ze[8].shape == (2, 2, 160)
   assert synthetic.flow_channels(hp) == [8, 8, 8, 8, 6, 6, 6, 6, 4, 4, 4, 4]
+
+
+def test_stft_oracle_is_self_consistent():
+  """oracle/stft_oracle.py (numpy restatement of stft.py / denoiser.py): the STFT pair reconstructs perfectly,
+  strength 0 is the identity, and the host-side bases handed to the library equal the oracle's."""
+  from oracle import stft_oracle as S
+  from waveglow_amd.denoiser import stft_bases
+  fwd, inv, wsq = S.bases()
+  x = np.random.default_rng(0).standard_normal((2, 256 * 9)) * 0.3
+  re, im = S.transform(x, fwd)
+  assert re.shape == (2, 513, 10)
+  assert np.abs(S.inverse(re, im, inv, wsq) - x).max() < 1e-12
+  assert np.abs(S.denoise(x, np.ones(513), 0.0, fwd, inv, wsq) - x).max() < 1e-12
+  d = S.denoise(x, np.full(513, 1e3), 1.0, fwd, inv, wsq)      # everything subtracted away
+  assert np.abs(d).max() < 1e-9
+  f32, i32, w32 = stft_bases()
+  assert f32.flags["C_CONTIGUOUS"] and i32.flags["C_CONTIGUOUS"]
+  np.testing.assert_allclose(f32, fwd, atol=1e-6)
+  np.testing.assert_allclose(i32, inv, atol=1e-6)
+  np.testing.assert_allclose(w32, wsq, atol=1e-6)

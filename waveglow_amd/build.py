@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libwaveglow_amd.so")
-SOURCES = ["kernels.hip", "api.cpp"]
+SOURCES = ["kernels.hip", "stft.hip", "api.cpp", "stft_api.cpp"]
 HEADERS = ["wg_common.h", os.path.join("..", "..", "include", "waveglow_amd.h")]
 
 

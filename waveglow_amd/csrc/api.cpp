@@ -204,6 +204,8 @@ struct Prof {
 
 }  // namespace
 
+int wg_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 const char* wg_version(void) { return "waveglow_amd 0.1 (gfx950)"; }
