@@ -141,6 +141,63 @@ int wg_stft_denoise(wg_stft* h, const float* audio, const float* bias_mag, float
                     float* mag0_out, int32_t B, int32_t n_samples, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* ---- Training direction: WaveGlow.forward under autograd and loss.backward() ---------------------------------------
+ * (src/waveglow/model.py:178-221, train.py:190-199).  Weights change every optimiser step, so they are NOT taken from
+ * the handle: the caller passes device buffers with every matrix row-major fp16 in "(pos,pos)" order -- rows and
+ * K columns permuted inside 32-blocks so that position 16h+4g+i holds channel 8g+4h+i (waveglow_amd/train.py builds
+ * them with differentiable torch ops, so weight norm and the folds below are differentiated by the caller's autograd).
+ * C = n_channels, M8 = 8*n_mel_channels, fl = flow*n_layers + layer, K1 = 3C + M8, h_k / c_k per flow.
+ * Needs only wg_create (no wg_set_tensor / wg_finalize). */
+typedef struct wg_train_weights {
+  const void* w1;      /* fp16 [FL][2C][K1]   in_layers (K = tap0 | tap1 | tap2, model.py:98-102) | cond_layer slice */
+  const float* b1;     /* [FL][2C]            in_layers.bias + cond_layer.bias slice */
+  const void* w2;      /* fp16 [FL][C][C]     res rows of res_skip_layers (model.py:131-134); last layer unused */
+  const float* b2;     /* [FL][C] */
+  const void* wes;     /* fp16 [FL][32][C]    end x skip fold: rows 0-7 hi, 8-15 lo fp16 halves of W_end.W_skip_i, rest 0 */
+  const void* wat;     /* fp16 [FL][C][C+64]  backward: [ W_res^T | (W_end.W_skip_i)^T padded to 64 ] */
+  const void* wbt;     /* fp16 [FL][C][6C]    backward: W_in[:, :, tap]^T for tap 0, 1, 2 */
+  const void* wct;     /* fp16 [M8][FL*2C]    backward: cond_layer^T of every layer */
+  const void* wup;     /* fp16 [32][M8][512]  upsample per phase p: row (o,g) , K = [tap j][128]: W_up[i][o][8p+g+256j] */
+  const float* bup;    /* [M8]                upsample.bias[o] repeated over g */
+  const float* const* wstart;    /* n_flows pointers: [C][h_k] fp32 */
+  const float* const* bstart;    /* [C] */
+  const float* const* out_init;  /* [8]   W_end.(sum_i b_skip_i) + b_end, zero padded */
+  const float* const* w1x1;      /* [c_k][c_k] fp32 row-major (model.py:64) */
+} wg_train_weights;
+
+/* Gradients (fp32 device buffers, same layouts as the weights they belong to; dwes is w.r.t. the effective
+ * end x skip matrix [8][C], dwup w.r.t. wup's layout). */
+typedef struct wg_train_grads {
+  float* dw1;          /* [FL][2C][K1] */
+  float* db1;          /* [FL][2C] */
+  float* dw2;          /* [FL][C][C]   (last layer of each flow: untouched) */
+  float* db2;          /* [FL][C] */
+  float* dwes;         /* [FL][8][C] */
+  float* dwup;         /* [32][M8][512] */
+  float* dbup;         /* [M8] */
+  float* const* dstart;      /* n_flows pointers: [5][C]: rows j < 4 = d Wstart[:, j] (zero for j >= h_k), row 4 = d bstart */
+  float* const* dout_init;   /* [8] */
+  float* const* dw1x1;       /* [8][8], top-left [c_k][c_k] used: the W.z term only; the logdet term (model.py:63) is
+                                the caller's */
+} wg_train_grads;
+
+size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len);
+
+/* Forward with saved activations.  mel [B][n_mel][n_frames] fp32, audio [B][audio_len] fp32 (audio_len % 8 == 0),
+ * z [B][8][L] fp32 out, log_s[k] [B][h_k][L] fp32 out.  `fresh` != 0: the workspace has not been used with this
+ * geometry before (it is cleared: guard rows must read as zero).  The workspace must stay untouched until
+ * wg_train_backward has run.  Enqueue-only. */
+int wg_train_forward(wg_handle* h, const wg_train_weights* w, const void* mel, const void* audio, float* z,
+                     float* const* log_s, int32_t B, int32_t n_frames, int32_t audio_len, int32_t fresh,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the last wg_train_forward on this workspace.  g_z [B][8][L] (or null), g_log_s[k] [B][h_k][L]
+ * (null entries = zero) are the gradients of the returned tensors; `scale` multiplies them on entry (fp16 gradient
+ * planes) and is divided out of every result.  Enqueue-only. */
+int wg_train_backward(wg_handle* h, const wg_train_weights* w, const wg_train_grads* grads, const float* g_z,
+                      const float* const* g_log_s, float scale, const void* audio, int32_t B, int32_t n_frames,
+                      int32_t audio_len, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Diagnostic builds only (-DWG_STAMPS): device buffer of n_tiles*8 uint64 that the WN-layer kernel fills with
  * s_memtime stamps at its phase boundaries (last launch wins).  A no-op pointer in the shipped library. */
 int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer);

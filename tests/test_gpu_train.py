@@ -1,0 +1,119 @@
+"""GPU parity of the TRAINING direction: forward with saved activations + the library's backward pass, against
+
+* tests/golden/c64_grads.npz -- gradients of the reference's own ``loss.backward()`` (make_golden_grads.py), and
+* oracle.grads_ref -- the CPU fp32 restatement (pinned bit-exact to that fixture in test_oracle_golden.py).
+
+Tolerance: the kernels use fp16 MFMA operands, fp16 saved activations and fp16 gradient planes (loss-scaled) with
+fp32 accumulation; per parameter tensor the gradient must match the fp32 reference to
+``||g - g_ref|| <= GRAD_TOL * ||g_ref||`` (+ a small absolute floor for tensors whose gradient is ~0).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _cases import oracle_cfg_from_hp
+from waveglow_amd import synthetic
+from waveglow_amd.hparams import HParams
+from waveglow_amd.model import WaveGlow, WaveGlowLoss
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 2e-2
+FWD_TOL = 2e-3
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _setup(over, B, T, wseed, crop=96):
+  hp = HParams(**over)
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=wseed))
+  mel = synthetic.make_mel(B, T, seed=1234 + B + T)
+  S = 256 * T - crop
+  g = torch.Generator().manual_seed(99 + T)
+  wav = torch.rand(B, S, generator=g) * 0.6 - 0.3
+  return hp, sd, mel, wav
+
+
+def _gpu_step(hp, sd, mel, wav, sigma=1.0):
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  model.zero_grad()
+  y = model((mel.cuda(), wav.cuda()))
+  loss = WaveGlowLoss(sigma)(y, None)
+  loss.backward()
+  torch.cuda.synchronize()
+  grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+  return float(loss), y, grads
+
+
+def _check(grads, ref, what):
+  worst = []
+  for name, g_ref in ref.items():
+    g = grads[name]
+    assert g.shape == g_ref.shape, name
+    assert torch.isfinite(g).all(), name
+    err = float((g - g_ref).norm())
+    den = float(g_ref.norm())
+    worst.append((err / max(den, 1e-12), name, err, den))
+  worst.sort(reverse=True)
+  for rel, name, err, den in worst[:8]:
+    print(f"{what}: {name}: rel {rel:.3e} (err {err:.3e}, ref norm {den:.3e})")
+  for rel, name, err, den in worst:
+    assert err <= GRAD_TOL * den + 1e-7, f"{name}: gradient error {err:.3e} vs norm {den:.3e}"
+
+
+def test_train_step_matches_reference_fixture_and_oracle():
+  from oracle import torch_oracle as O
+  over = dict(n_channels=64, n_layers=4, n_flows=6, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 12, 5)
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  fx = np.load(os.path.join(HERE, "golden", "c64_grads.npz"))
+  print(f"loss gpu {loss:.6f} reference {float(fx['loss']):.6f}")
+  assert abs(loss - float(fx["loss"])) <= 2e-3 * max(1.0, abs(float(fx["loss"])))
+  # forward outputs vs the oracle
+  cfg = oracle_cfg_from_hp(hp)
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, cfg, 1.0)
+  assert abs(float(loss_ref) - float(fx["loss"])) < 1e-6
+  _check(grads, g_ref, "c64")
+  # and directly against what the reference wrote down
+  for key in fx.files:
+    if key.startswith("full/"):
+      name = key[5:]
+      ref = torch.from_numpy(fx[key])
+      err = float((grads[name] - ref).norm())
+      assert err <= GRAD_TOL * float(ref.norm()) + 1e-7, name
+    elif key.startswith("norm/"):
+      name = key[5:]
+      assert abs(float(grads[name].norm()) - float(fx[key])) <= GRAD_TOL * float(fx[key]) + 1e-7, name
+
+
+def test_train_forward_outputs_match_oracle():
+  from oracle import torch_oracle as O
+  over = dict(n_channels=64, n_layers=4, n_flows=6, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 12, 5)
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  z, log_s, log_det = model((mel.cuda(), wav.cuda()))
+  dense = {k: v.detach().cpu() for k, v in model.dense_state().items()}
+  z_ref, ls_ref, ld_ref = O.forward_ref(dense, mel, wav, oracle_cfg_from_hp(hp))
+  ez = float((z.cpu() - z_ref).pow(2).mean().sqrt())
+  print("z rms err", ez)
+  assert ez <= FWD_TOL
+  for a, b in zip(log_s, ls_ref):
+    assert float((a.cpu() - b).pow(2).mean().sqrt()) <= FWD_TOL
+  for a, b in zip(log_det, ld_ref):
+    assert abs(float(a) - float(b)) <= 1e-3 * max(1.0, abs(float(b)))
+
+
+def test_train_step_c256_two_utterances():
+  """Full-width model (256 channels, 8 layers, 12 flows), ragged length: every parameter gradient vs the oracle."""
+  from oracle import torch_oracle as O
+  hp, sd, mel, wav = _setup(dict(), 2, 9, 3, crop=40)
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  print(f"loss gpu {loss:.6f} oracle {float(loss_ref):.6f}")
+  assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check(grads, g_ref, "c256")

@@ -21,6 +21,18 @@ class WgConfig(C.Structure):
     "n_channels", "kernel_size", "upsample_kernel", "upsample_stride")]
 
 
+class WgTrainWeights(C.Structure):
+  """wg_train_weights (include/waveglow_amd.h): device pointers; the last four are arrays of n_flows pointers."""
+  _fields_ = [(n, C.c_void_p) for n in (
+    "w1", "b1", "w2", "b2", "wes", "wat", "wbt", "wct", "wup", "bup", "wstart", "bstart", "out_init", "w1x1")]
+
+
+class WgTrainGrads(C.Structure):
+  """wg_train_grads: device pointers; the last three are arrays of n_flows pointers."""
+  _fields_ = [(n, C.c_void_p) for n in (
+    "dw1", "db1", "dw2", "db2", "dwes", "dwup", "dbup", "dstart", "dout_init", "dw1x1")]
+
+
 class WgError(RuntimeError):
   pass
 
@@ -47,6 +59,13 @@ SIGNATURES = {
   "wg_loss": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
                         C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_macs_per_group_step": (C.c_double, [C.c_void_p]),
+  "wg_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+  "wg_train_forward": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+  "wg_train_backward": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.POINTER(WgTrainGrads), C.c_void_p,
+                                  C.POINTER(C.c_void_p), C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_stft_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
   "wg_stft_destroy": (C.c_int, [C.c_void_p]),
   "wg_stft_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -8,8 +8,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libwaveglow_amd.so")
-SOURCES = ["kernels.hip", "stft.hip", "api.cpp", "stft_api.cpp"]
-HEADERS = ["wg_common.h", os.path.join("..", "..", "include", "waveglow_amd.h")]
+SOURCES = ["kernels.hip", "stft.hip", "train.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"]
+HEADERS = ["wg_common.h", "wg_train.h", os.path.join("..", "..", "include", "waveglow_amd.h")]
 
 
 def _hipcc() -> str:

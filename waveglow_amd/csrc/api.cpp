@@ -206,6 +206,11 @@ struct Prof {
 
 int wg_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 
+// accessors for the other translation units of the library (train_api.cpp)
+const wg_config* wg_internal_config(const wg_handle* h) { return h ? &h->cfg : nullptr; }
+const int* wg_internal_flow_channels(const wg_handle* h) { return h ? h->c_k.data() : nullptr; }
+wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T) { return make_geom(h->cfg, B, L, T); }
+
 extern "C" {
 
 const char* wg_version(void) { return "waveglow_amd 0.1 (gfx950)"; }
@@ -608,6 +613,8 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
     f.sigma = sigma;
     f.Z = w.Z;
     f.out = w.OUT;
+    f.Z_w = w.Z;
+    f.out_w = w.OUT;
     f.g = g;
     f.C = C;
     f.io_f16 = io_dtype == WG_F16;
@@ -701,6 +708,8 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
     f.direction = 1;
     f.Z = w.Z;
     f.out = w.OUT;
+    f.Z_w = w.Z;
+    f.out_w = w.OUT;
     f.g = g;
     f.C = C;
     f.io_f16 = io_dtype == WG_F16;

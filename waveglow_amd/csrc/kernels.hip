@@ -877,10 +877,10 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
         }
       }
       if (!a.last) {
-        float4* zp = (float4*)(a.Z + row * 8);
+        float4* zp = (float4*)(a.Z_w + row * 8);
         zp[0] = make_float4(zn[0], zn[1], zn[2], zn[3]);
         zp[1] = make_float4(zn[4], zn[5], zn[6], zn[7]);
-        float4* op = (float4*)(a.out + row * 8);
+        float4* op = (float4*)(a.out_w + row * 8);
         op[0] = make_float4(a.out_init[0], a.out_init[1], a.out_init[2], a.out_init[3]);
         op[1] = make_float4(a.out_init[4], a.out_init[5], a.out_init[6], a.out_init[7]);
         s_a0[tid] = make_float4(zn[0], zn[1], zn[2], zn[3]);

@@ -1,0 +1,654 @@
+// gfx950 kernels of the TRAINING direction: WaveGlow.forward with saved activations and its backward pass
+// (reference: src/waveglow/model.py:178-221 under autograd, train.py:190-199 loss.backward()).
+//
+//   plane_gemm_kernel<EPI>  D = A . B over fp16 planes (B = runs of 64-channel planes read at tap offsets), with the
+//                           epilogues of wg_train.h: gate (+ saved tanh / sigmoid), residual add, folded end x skip,
+//                           gate derivative.  Forward GEMM 1 / GEMM 2, both dgrads, the upsample and its dgrad all
+//                           go through it.
+//   wgrad_kernel            dW = G^T-contracted-over-rows X: both operands are [row][channel] planes, so the MFMA
+//                           fragments are fetched with the transposing LDS read ds_read_b64_tr_b16.
+//   row kernels             coupling / 1x1 / start backward, column sums, slab reduction, mel planes.
+//
+// First correct version of this path: compiler-managed waits, register-staged LDS tiles, one barrier per K-step
+// (the hand-scheduled inference kernel in kernels.hip is the template for tuning it).
+#include "wg_train.h"
+
+namespace wg {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+namespace {
+
+__device__ __forceinline__ int pos_local(int r) {   // chan_to_pos for r < 32
+  return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+}
+
+// plane row of tile-local row rr of phase p shifted by dt group-timesteps (RowGeom)
+__device__ __forceinline__ size_t shifted_row(const RowGeom& g, int p, int dt) {
+  const int pp = p + dt;
+  return (size_t)((long long)kRowPad + (long long)(pp & 31) * g.Rp + (pp >> 5));
+}
+
+__device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, int& b, int& t) {
+  b = rr / g.Fp;
+  const int f = rr - b * g.Fp - g.Gf;
+  t = 32 * f + p;
+  return b < g.B && f >= 0 && f < g.F && t < g.L;
+}
+
+}  // namespace
+
+// =============================================================================================
+// plane GEMM.  Workgroup = 8 waves = one tile of 128 consecutive rows of one phase x 256 matrix rows (x 2 halves for
+// the gate); wave w owns the 32-row block (8*blockIdx.y + w).  K-step = one 64-channel plane chunk: the B tile
+// (128 rows x 128 B) goes global -> registers -> LDS (XOR-swizzled 16-byte pieces, double buffered, one barrier per
+// step); A fragments come straight from the row-major matrix: lane (r, h) reads the 64 contiguous bytes
+// A[row r][k0 + 32h ..], i.e. element j of MFMA sub-step s is k = 32h + 8s + j, and the B fragment of that sub-step
+// is LDS piece 4h + s of the lane's column -- the K order inside a step is free as long as both operands agree.
+// =============================================================================================
+template <int EPI>
+__global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
+  constexpr int MT = (EPI == EPI_GATE) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) _Float16 sB[2][128 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const RowGeom& g = a.g;
+  const int tpp = g.Rp >> 7;
+  const int tile = blockIdx.x;
+  const int p = tile / tpp, r0 = (tile - p * tpp) << 7;
+  const int blk = blockIdx.y * 8 + w;
+  const bool active = blk * 32 < a.M;
+  const size_t R64 = (size_t)g.R * 64;
+
+  const _Float16* Ap = a.A + (size_t)p * a.a_phase_stride;
+  const int mrow = (active ? blk * 32 : 0) + pos_local(r);
+  const _Float16* arow[MT];
+  arow[0] = Ap + (size_t)mrow * a.lda + 32 * h;
+  if (MT == 2) arow[MT - 1] = Ap + (size_t)(a.M + mrow) * a.lda + 32 * h;
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mt][ct][j] = 0.0f;
+
+  int n_steps = 0;
+  for (int i = 0; i < a.n_runs; ++i) n_steps += a.run[i].n_chunks;
+
+  // B-tile staging: thread -> pieces tid and tid + 512 of 1024 (row = idx >> 3, piece = idx & 7)
+  const int brow0 = tid >> 3, bpc = tid & 7;
+  const int lds_w0 = brow0 * 64 + ((bpc ^ (brow0 & 7)) << 3);
+  const int lds_w1 = (brow0 + 64) * 64 + ((bpc ^ (brow0 & 7)) << 3);   // (brow0 + 64) & 7 == brow0 & 7
+  half8 bn0, bn1, an[MT][4], ac[MT][4];
+
+  int ri = 0, ci = 0;   // run / chunk of the step being FETCHED
+  auto fetch = [&](int step) {
+    const PRun& R = a.run[ri];
+    const _Float16* src = R.base + (size_t)ci * R64 + (shifted_row(g, p, R.dt) + r0) * 64;
+    bn0 = *(const half8*)(src + (size_t)brow0 * 64 + bpc * 8);
+    bn1 = *(const half8*)(src + (size_t)(brow0 + 64) * 64 + bpc * 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) an[mt][s] = *(const half8*)(arow[mt] + (size_t)step * 64 + 8 * s);
+    if (++ci == R.n_chunks) { ci = 0; ++ri; }
+  };
+  auto commit = [&](int buf) {
+    *(half8*)&sB[buf][lds_w0] = bn0;
+    *(half8*)&sB[buf][lds_w1] = bn1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ac[mt][s] = an[mt][s];
+  };
+
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int st = 0; st < n_steps; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < n_steps;
+    half8 a_use[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a_use[mt][s] = ac[mt][s];
+    if (more) fetch(st + 1);
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        half8 bf[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          bf[ct] = *(const half8*)&sB[buf][(ct * 32 + r) * 64 + (((4 * h + s) ^ (r & 7)) << 3)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[mt][s], bf[ct], acc[mt][ct], 0, 0, 0);
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+  }
+  if (!active) return;
+
+  // ---- epilogue: lane (column r of column tile ct, half h) holds matrix positions P0 .. P0+15 of its 32-block
+  const int P0 = blk * 32 + 16 * h;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int rr = r0 + ct * 32 + r;
+    int b, t;
+    const bool valid = column_valid(g, p, rr, b, t);
+    const size_t prow = (size_t)kRowPad + (size_t)p * g.Rp + rr;
+    const size_t addr = ((size_t)(P0 >> 6) * g.R + prow) * 64 + (P0 & 63);
+    if (EPI == EPI_GATE) {
+      half8 T0, T1, S0, S1, A0, A1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float u = acc[0][ct][j] + a.bias[P0 + j];
+        const float v = acc[MT - 1][ct][j] + a.bias[a.M + P0 + j];
+        // tanh(u) = 1 - 2/(1 + e^{2u}),  sigmoid(v) = 1/(1 + e^{-v})            (model.py:17-18)
+        float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
+        float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+        if (!valid) { th = 0.0f; sg = 0.0f; }
+        const _Float16 th16 = (_Float16)th, sg16 = (_Float16)sg;
+        // acts from the ROUNDED factors: the backward pass sees exactly the saved T and S
+        const _Float16 ac16 = (_Float16)((float)th16 * (float)sg16);
+        if (j < 8) { T0[j] = th16; S0[j] = sg16; A0[j] = ac16; }
+        else { T1[j - 8] = th16; S1[j - 8] = sg16; A1[j - 8] = ac16; }
+      }
+      *(half8*)(a.o0 + addr) = T0; *(half8*)(a.o0 + addr + 8) = T1;
+      *(half8*)(a.o1 + addr) = S0; *(half8*)(a.o1 + addr + 8) = S1;
+      *(half8*)(a.o2 + addr) = A0; *(half8*)(a.o2 + addr + 8) = A1;
+    } else if (EPI == EPI_RES) {
+      half8 in0, in1, o0, o1;
+      if (a.i0) { in0 = *(const half8*)(a.i0 + addr); in1 = *(const half8*)(a.i0 + addr + 8); }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float v = acc[0][ct][j];
+        if (a.bias) v += a.bias[P0 + j];
+        if (a.i0) v += (float)(j < 8 ? in0[j & 7] : in1[j & 7]);
+        if (!valid) v = 0.0f;
+        if (j < 8) o0[j] = (_Float16)v; else o1[j - 8] = (_Float16)v;
+      }
+      *(half8*)(a.o0 + addr) = o0; *(half8*)(a.o0 + addr + 8) = o1;
+    } else if (EPI == EPI_ES) {
+      // matrix rows (natural order) 0-7 = hi, 8-15 = lo halves of the folded end x skip rows: MFMA row
+      // 8(j>>2) + 4h + (j&3), so lane half h holds output channels 4h .. 4h+3 as acc[i] (hi) + acc[4+i] (lo)
+      if (blk == 0 && valid) {
+        float4* op = (float4*)(a.rows32 + ((size_t)b * g.L + t) * 8 + 4 * h);
+        float4 o = *op;
+        o.x += acc[0][ct][0] + acc[0][ct][4];
+        o.y += acc[0][ct][1] + acc[0][ct][5];
+        o.z += acc[0][ct][2] + acc[0][ct][6];
+        o.w += acc[0][ct][3] + acc[0][ct][7];
+        *op = o;
+      }
+    } else if (EPI == EPI_DGATE) {
+      const half8 T0 = *(const half8*)(a.i0 + addr), T1 = *(const half8*)(a.i0 + addr + 8);
+      const half8 S0 = *(const half8*)(a.i1 + addr), S1 = *(const half8*)(a.i1 + addr + 8);
+      half8 gt0, gt1, gs0, gs1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float th = (float)(j < 8 ? T0[j & 7] : T1[j & 7]);
+        const float sg = (float)(j < 8 ? S0[j & 7] : S1[j & 7]);
+        const float ga = valid ? acc[0][ct][j] : 0.0f;
+        const float gt = ga * sg * (1.0f - th * th);      // d/du tanh(u) sigmoid(v)
+        const float gs = ga * th * sg * (1.0f - sg);      // d/dv
+        if (j < 8) { gt0[j] = (_Float16)gt; gs0[j] = (_Float16)gs; }
+        else { gt1[j - 8] = (_Float16)gt; gs1[j - 8] = (_Float16)gs; }
+      }
+      const int Ps = a.M + P0;
+      const size_t addr_s = ((size_t)(Ps >> 6) * g.R + prow) * 64 + (Ps & 63);
+      *(half8*)(a.o0 + addr) = gt0; *(half8*)(a.o0 + addr + 8) = gt1;
+      *(half8*)(a.o0 + addr_s) = gs0; *(half8*)(a.o0 + addr_s + 8) = gs1;
+    }
+  }
+}
+
+hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
+  if (a.g.Rp % 128 || a.n_runs < 1 || a.n_runs > kMaxRuns || a.M < 1) return hipErrorInvalidValue;
+  int k = 0;
+  for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks * 64;
+  if (k != a.ktot) return hipErrorInvalidValue;
+  dim3 grid(kPhases * (a.g.Rp / 128), (a.M + 255) / 256);
+  switch (epi) {
+    case EPI_STORE16:
+    case EPI_RES: hipLaunchKernelGGL(plane_gemm_kernel<EPI_RES>, grid, dim3(512), 0, s, a); break;
+    case EPI_GATE: hipLaunchKernelGGL(plane_gemm_kernel<EPI_GATE>, grid, dim3(512), 0, s, a); break;
+    case EPI_ES: hipLaunchKernelGGL(plane_gemm_kernel<EPI_ES>, grid, dim3(512), 0, s, a); break;
+    case EPI_DGATE: hipLaunchKernelGGL(plane_gemm_kernel<EPI_DGATE>, grid, dim3(512), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Weight gradient.  out[phase][m][k'] = sum_rows G[row][m] X[row + shift][k'] over the Rp rows of one phase.
+// Workgroup = 4 waves = a 128 (m) x 128 (k') output tile of one phase; wave (wm, wk) owns the 64 x 64 quadrant.
+// Both operands are [row][channel] planes and the contraction runs over ROWS, so an MFMA fragment (8 consecutive
+// k = rows, one channel per lane) is a column of the LDS tile: fetched with ds_read_b64_tr_b16, which hands lane i
+// of a 16-lane group column i of a 4-row x 16-column block (cdna_hip_programming.md T10).  LDS rows are padded
+// to 320 B so that the 4 rows x 64 B a 32-lane half touches fall on 64 distinct banks.
+// Guard / invalid rows of G are zero by construction (every producer writes zeros there), so no masking.
+// =============================================================================================
+constexpr int WG_RS = 160;      // LDS row stride in halves
+constexpr int WG_STEP = 32;     // rows per step
+
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 sG[2][WG_STEP * WG_RS];
+  __shared__ __attribute__((aligned(16))) _Float16 sX[2][WG_STEP * WG_RS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wk = w & 1;
+  const RowGeom& g = a.g;
+  const int p = blockIdx.z;
+  const int mc0 = blockIdx.x * 2, kc0 = blockIdx.y * 2;
+  const size_t R64 = (size_t)g.R * 64;
+
+  // staging: thread -> 2 pieces per operand: idx = tid, tid + 256: row = idx >> 4, half e = (idx >> 3) & 1, piece = idx & 7
+  const int srow = tid >> 4, se = (tid >> 3) & 1, spc = tid & 7;
+  const _Float16* gsrc = nullptr;
+  if (mc0 + se < a.m_chunks) gsrc = a.G + (size_t)(mc0 + se) * R64 + ((size_t)kRowPad + (size_t)p * g.Rp) * 64;
+  const _Float16* xsrc = nullptr;
+  {
+    int c = kc0 + se;
+    for (int i = 0; i < a.n_runs; ++i) {
+      if (c < a.run[i].n_chunks) {
+        xsrc = a.run[i].base + (size_t)c * R64 + shifted_row(g, p, a.run[i].dt) * 64;
+        break;
+      }
+      c -= a.run[i].n_chunks;
+    }
+  }
+  const int lds_w = srow * WG_RS + se * 64 + spc * 8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][k][j] = 0.0f;
+
+  half8 gn[2], xn[2];
+  auto fetch = [&](int st) {
+    const size_t ro = (size_t)(st * WG_STEP + srow) * 64 + spc * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      half8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.0f;
+      gn[q] = gsrc ? *(const half8*)(gsrc + ro + (size_t)q * 16 * 64) : z;
+      xn[q] = xsrc ? *(const half8*)(xsrc + ro + (size_t)q * 16 * 64) : z;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *(half8*)&sG[buf][lds_w + q * 16 * WG_RS] = gn[q];
+      *(half8*)&sX[buf][lds_w + q * 16 * WG_RS] = xn[q];
+    }
+  };
+
+  // transposing fragment read: lane = 16*g16 + u; MFMA operand lane (r = lane & 31, hh = lane >> 5) needs rows
+  // 16s + 8hh + j (j < 8) of channel r: two 4-row blocks, lane (q = u >> 2, pq = u & 3) addresses row q, cols 4pq..
+  const int g16 = lane >> 4, hh = g16 >> 1, hf = g16 & 1, u = lane & 15;
+  const int tr_off = (8 * hh + (u >> 2)) * WG_RS + 16 * hf + 4 * (u & 3);
+  auto frag = [&](const _Float16* tile, int col0, int s) -> half8 {
+    const _Float16* q0 = tile + tr_off + 16 * s * WG_RS + col0;
+    const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)q0);
+    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 4 * WG_RS));
+    const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+    return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  const int n_steps = g.Rp / WG_STEP;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int st = 0; st < n_steps; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < n_steps;
+    if (more) fetch(st + 1);
+#pragma unroll
+    for (int s = 0; s < WG_STEP / 16; ++s) {
+      half8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = frag(sG[buf], wm * 64 + 32 * i, s);
+        bf[i] = frag(sX[buf], wk * 64 + 32 * i, s);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[k], acc[i][k], 0, 0, 0);
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int Mtot = a.m_chunks * 64, Ktot = a.k_chunks * 64;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m0 = (mc0 + wm) * 64 + 32 * i;
+    if (m0 >= Mtot) continue;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int kk = (kc0 + wk) * 64 + 32 * k + r;
+      if (kk >= Ktot) continue;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = m0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+        a.out[((size_t)p * Mtot + m) * Ktot + kk] = acc[i][k][j] * a.out_scale;
+      }
+    }
+  }
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  if (a.g.Rp % WG_STEP || a.n_runs < 1 || a.n_runs > kMaxRuns) return hipErrorInvalidValue;
+  int k = 0;
+  for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks;
+  if (k != a.k_chunks) return hipErrorInvalidValue;
+  dim3 grid((a.m_chunks + 1) / 2, (a.k_chunks + 1) / 2, kPhases);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible)
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, size_t stride,
+                                                          size_t n, float scale, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float s = 0.0f;
+    for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * stride + i];
+    out[i] = s * scale;
+  }
+}
+
+hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
+                              hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, n_slabs, stride, n, scale, out);
+  return hipGetLastError();
+}
+
+// per-channel sums over the rows of planes: grid (Rp/128, 32 phases, n_chunks) -> partial[(p * Rp/128 + x)][chunk*64 + ch]
+__global__ void __launch_bounds__(256) colsum_kernel(const _Float16* __restrict__ planes, int n_chunks, RowGeom g,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int ch = threadIdx.x & 63, rs = threadIdx.x >> 6;
+  const int p = blockIdx.y, chunk = blockIdx.z;
+  const _Float16* src = planes + ((size_t)chunk * g.R + kRowPad + (size_t)p * g.Rp + (size_t)blockIdx.x * 128) * 64 + ch;
+  float s = 0.0f;
+  for (int r = rs; r < 128; r += 4) s += (float)src[(size_t)r * 64];
+  red[rs][ch] = s;
+  __syncthreads();
+  if (rs == 0) {
+    const size_t slab = (size_t)p * gridDim.x + blockIdx.x;
+    partial[slab * ((size_t)n_chunks * 64) + chunk * 64 + ch] = red[0][ch] + red[1][ch] + red[2][ch] + red[3][ch];
+  }
+}
+
+int colsum_slabs(const RowGeom& g) { return kPhases * (g.Rp / 128); }
+
+hipError_t launch_colsum(const _Float16* planes, int n_chunks, const RowGeom& g, float* partial, hipStream_t s) {
+  dim3 grid(g.Rp / 128, kPhases, n_chunks);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, planes, n_chunks, g, partial);
+  return hipGetLastError();
+}
+
+// mel [B][M][T] -> planes [2 chunks][R][64]: row (p, b, q) = mel[b][:, q] (natural channel order, zero padded to 128),
+// identical for every phase; rows of guard frames and frames >= T are zero (transposed-conv padding, model.py:145).
+__global__ void __launch_bounds__(256) mel_plane_kernel(const void* __restrict__ mel, int io_f16, int M, RowGeom g,
+                                                        _Float16* __restrict__ melp) {
+  const size_t n = (size_t)kPhases * g.Rp * 128;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+    const int i = (int)(idx & 127);
+    const size_t row = idx >> 7;                       // p * Rp + rr
+    const int rr = (int)(row % g.Rp);
+    const int b = rr / g.Fp, f = rr - b * g.Fp - g.Gf;
+    float v = 0.0f;
+    if (i < M && b < g.B && f >= 0 && f < g.T) {
+      const size_t src = ((size_t)b * M + i) * g.T + f;
+      v = io_f16 ? (float)((const _Float16*)mel)[src] : ((const float*)mel)[src];
+    }
+    melp[((size_t)(i >> 6) * g.R + kRowPad + row) * 64 + (i & 63)] = (_Float16)v;
+  }
+}
+
+hipError_t launch_mel_plane(const void* mel, int io_f16, int M, const RowGeom& g, _Float16* melp, hipStream_t s) {
+  if (M > 128) return hipErrorInvalidValue;
+  size_t blocks = ((size_t)kPhases * g.Rp * 128 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mel_plane_kernel, dim3((unsigned)blocks), dim3(256), 0, s, mel, io_f16, M, g, melp);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Flow backward, part 1 (before the WN backward): affine coupling  a1' = exp(log_s) a1 + b  (model.py:213-216).
+//   d b = d a1',  d log_s = d log_s(ext) + d a1' * exp(log_s) * a1,  d a1 = d a1' * exp(log_s)
+// (d b | d log_s) is the gradient of the WN output: written as the fp16 K-segment plane of the backward GEMM.
+// =============================================================================================
+constexpr int FB_ROWS = 256;
+
+__global__ void __launch_bounds__(FB_ROWS) flow_bwd_pre_kernel(const FlowBwdArgs a) {
+  const int L = a.g.L;
+  const size_t nrows = (size_t)a.g.B * L;
+  const size_t row = (size_t)blockIdx.x * FB_ROWS + threadIdx.x;
+  if (row >= nrows) return;
+  const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+  const int h = a.h, c = a.c;
+  float go[kMaxGroup], z[kMaxGroup], o[kMaxGroup];
+  {
+    const float4* zp = (const float4*)(a.Zpost + row * 8);
+    const float4* op = (const float4*)(a.OUT + row * 8);
+    const float4 z0 = zp[0], z1 = zp[1], o0 = op[0], o1 = op[1];
+    z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
+    o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
+  }
+  if (a.from_z) {
+#pragma unroll
+    for (int j = 0; j < kMaxGroup; ++j)
+      go[j] = (j < c && a.g_z) ? a.scale * a.g_z[((size_t)b * 8 + a.z_ch0 + j) * L + t] : 0.0f;
+  } else {
+    const float4* gp = (const float4*)(a.GZ + row * 8);
+    const float4 g0 = gp[0], g1 = gp[1];
+    go[0] = g0.x; go[1] = g0.y; go[2] = g0.z; go[3] = g0.w; go[4] = g1.x; go[5] = g1.y; go[6] = g1.z; go[7] = g1.w;
+  }
+  float ga[kMaxGroup], gout[kMaxGroup];
+#pragma unroll
+  for (int j = 0; j < kMaxGroup; ++j) { ga[j] = 0.0f; gout[j] = 0.0f; }
+#pragma unroll
+  for (int j = 0; j < kMaxGroup; ++j) {
+    if (j < h) ga[j] = go[j];                             // d a0 (direct part)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (j >= h && j - h == q && q < h) {
+        const float e = expf(o[j]);                       // o[h+q] = log_s_q, o[q] = b_q
+        const float gy = go[j];
+        float gls = gy * e * z[j];
+        if (a.g_log_s) gls += a.scale * a.g_log_s[((size_t)b * h + q) * L + t];
+        ga[j] = gy * e;                                   // d a1
+        gout[q] = gy;                                     // d b
+        gout[j] = gls;                                    // d log_s
+      }
+  }
+  float4* gp = (float4*)(a.GZ + row * 8);
+  gp[0] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+  gp[1] = make_float4(ga[4], ga[5], ga[6], ga[7]);
+  half8 o16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o16[j] = (_Float16)gout[j];
+  const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
+  *(half8*)(a.GO + prow * 64) = o16;
+}
+
+// Flow backward, part 2 (after the WN backward): start conv, 1x1 conv, peel.
+//   d a0 += Wstart^T d x_0 ;  d(W z)= (d a0 | d a1) ;  d z_in = W^T d(W z) ;  d W += d(W z) z_in^T  (model.py:64, :117)
+__global__ void __launch_bounds__(FB_ROWS) flow_bwd_post_kernel(const FlowBwdArgs a) {
+  __shared__ float s_g[FB_ROWS][9];
+  __shared__ float s_x[FB_ROWS][9];
+  const int L = a.g.L;
+  const size_t nrows = (size_t)a.g.B * L;
+  const size_t row = (size_t)blockIdx.x * FB_ROWS + threadIdx.x;
+  const int h = a.h, c = a.c;
+  float gy[kMaxGroup], xin[kMaxGroup];
+#pragma unroll
+  for (int j = 0; j < kMaxGroup; ++j) { gy[j] = 0.0f; xin[j] = 0.0f; }
+  if (row < nrows) {
+    const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+    const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
+    {
+      const float4* gp = (const float4*)(a.GZ + row * 8);
+      const float4 g0 = gp[0], g1 = gp[1];
+      gy[0] = g0.x; gy[1] = g0.y; gy[2] = g0.z; gy[3] = g0.w; gy[4] = g1.x; gy[5] = g1.y; gy[6] = g1.z; gy[7] = g1.w;
+    }
+    float wn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int cc = 0; cc < a.C / 64; ++cc) {
+      const half8* xp = (const half8*)(a.GX + ((size_t)cc * a.g.R + prow) * 64);
+#pragma unroll
+      for (int v8 = 0; v8 < 8; ++v8) {
+        const half8 x = xp[v8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int P = cc * 64 + v8 * 8 + e;
+          const float xv = (float)x[e];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < h) wn[j] = fmaf(a.wstart[P * h + j], xv, wn[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < h) gy[j] += wn[j];
+    // input of this flow's 1x1 conv
+    if (a.Zprev) {
+      const float4* zp = (const float4*)(a.Zprev + row * 8);
+      const float4* op = (const float4*)(a.OUTprev + row * 8);
+      const float4 z0 = zp[0], z1 = zp[1], o0 = op[0], o1 = op[1];
+      float z[kMaxGroup], o[kMaxGroup], y[kMaxGroup];
+      z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
+      o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
+      const int hp = a.h_prev;
+#pragma unroll
+      for (int j = 0; j < kMaxGroup; ++j) {
+        y[j] = z[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j >= hp && j - hp == q && q < hp) y[j] = expf(o[j]) * z[j] + o[q];
+      }
+#pragma unroll
+      for (int e = 0; e < kMaxGroup; ++e) {
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kMaxGroup; ++q)
+          if (q - a.n_peel == e) v = y[q];
+        xin[e] = (e < c) ? v : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < kMaxGroup; ++e) xin[e] = a.audio[(size_t)b * L * 8 + (size_t)t * 8 + e];
+    }
+    if (a.Zprev) {
+      // d(previous flow's output) = (d z[peeled channels] | W^T d(W z))
+      float gin[kMaxGroup], gz[kMaxGroup];
+#pragma unroll
+      for (int cc = 0; cc < kMaxGroup; ++cc) {
+        float s = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < kMaxGroup; ++rr)
+          if (rr < c && cc < c) s = fmaf(a.w1x1[rr * c + cc], gy[rr], s);
+        gin[cc] = s;
+      }
+#pragma unroll
+      for (int e = 0; e < kMaxGroup; ++e) {
+        float v = 0.0f;
+        if (e < a.n_peel && a.g_z) v = a.scale * a.g_z[((size_t)b * 8 + a.z_peel_ch0 + e) * L + t];
+#pragma unroll
+        for (int q = 0; q < kMaxGroup; ++q)
+          if (e >= a.n_peel && e - a.n_peel == q && q < c) v = gin[q];
+        gz[e] = v;
+      }
+      float4* gp = (float4*)(a.GZ + row * 8);
+      gp[0] = make_float4(gz[0], gz[1], gz[2], gz[3]);
+      gp[1] = make_float4(gz[4], gz[5], gz[6], gz[7]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxGroup; ++j) {
+    s_g[threadIdx.x][j] = (j < c) ? gy[j] : 0.0f;
+    s_x[threadIdx.x][j] = xin[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int rr = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    float s = 0.0f;
+    for (int i = 0; i < FB_ROWS; ++i) s = fmaf(s_g[i][rr], s_x[i][cc], s);
+    a.dw_partial[(size_t)blockIdx.x * 64 + threadIdx.x] = s;
+  }
+}
+
+int flow_bwd_workgroups(const RowGeom& g) { return (int)(((size_t)g.B * g.L + FB_ROWS - 1) / FB_ROWS); }
+
+hipError_t launch_flow_bwd_pre(const FlowBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(flow_bwd_pre_kernel, dim3(flow_bwd_workgroups(a.g)), dim3(FB_ROWS), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_flow_bwd_post(const FlowBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(flow_bwd_post_kernel, dim3(flow_bwd_workgroups(a.g)), dim3(FB_ROWS), 0, s, a);
+  return hipGetLastError();
+}
+
+// d Wstart[P][j] = sum_rows d x_0[row][P] a0[row][j],  d bstart[P] = sum_rows d x_0[row][P]     (model.py:117)
+// grid (Rp/128, 32): 128 plane rows of one phase; thread -> channel position(s).
+__global__ void __launch_bounds__(256) start_wgrad_kernel(const StartWgradArgs a) {
+  __shared__ float4 s_a0[128];
+  const RowGeom& g = a.g;
+  const int p = blockIdx.y, r0 = blockIdx.x * 128;
+  if (threadIdx.x < 128) {
+    int b, t;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (column_valid(g, p, r0 + threadIdx.x, b, t)) {
+      const float4 z = *(const float4*)(a.Zpost + ((size_t)b * g.L + t) * 8);
+      v.x = z.x;
+      v.y = a.h > 1 ? z.y : 0.f;
+      v.z = a.h > 2 ? z.z : 0.f;
+      v.w = a.h > 3 ? z.w : 0.f;
+    }
+    s_a0[threadIdx.x] = v;
+  }
+  __syncthreads();
+  const size_t slab = (size_t)p * gridDim.x + blockIdx.x;
+  for (int P = threadIdx.x; P < a.C; P += 256) {
+    const _Float16* src = a.GX + ((size_t)(P >> 6) * g.R + kRowPad + (size_t)p * g.Rp + r0) * 64 + (P & 63);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sb = 0.f;
+    for (int r = 0; r < 128; ++r) {
+      const float x = (float)src[(size_t)r * 64];
+      const float4 a0 = s_a0[r];
+      s0 = fmaf(x, a0.x, s0); s1 = fmaf(x, a0.y, s1); s2 = fmaf(x, a0.z, s2); s3 = fmaf(x, a0.w, s3);
+      sb += x;
+    }
+    float* o = a.partial + slab * 5 * a.C;
+    o[0 * a.C + P] = s0; o[1 * a.C + P] = s1; o[2 * a.C + P] = s2; o[3 * a.C + P] = s3; o[4 * a.C + P] = sb;
+  }
+}
+
+int start_wgrad_workgroups(const RowGeom& g) { return kPhases * (g.Rp / 128); }
+
+hipError_t launch_start_wgrad(const StartWgradArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(start_wgrad_kernel, dim3(a.g.Rp / 128, kPhases), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace wg

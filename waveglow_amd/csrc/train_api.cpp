@@ -1,0 +1,480 @@
+// C ABI of the training direction (include/waveglow_amd.h: wg_train_*): launch sequencing of train.hip.
+// Reference: WaveGlow.forward under autograd (src/waveglow/model.py:178-221) and loss.backward() (train.py:190-199).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/waveglow_amd.h"
+#include "wg_train.h"
+
+using namespace wg;
+
+int wg_set_error(int code, const char* msg);                              // api.cpp
+const wg_config* wg_internal_config(const wg_handle* h);                  // api.cpp
+const int* wg_internal_flow_channels(const wg_handle* h);                 // api.cpp
+wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T);    // api.cpp
+
+namespace {
+
+#define TR_TRY(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      std::string m = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+      return wg_set_error(WG_ERR_HIP, m.c_str());                                            \
+    }                                                                                        \
+    if (dbg_sync()) {                                                                        \
+      hipError_t _s = hipStreamSynchronize(s);                                               \
+      fprintf(stderr, "[wg-train] %s -> %s\n", #expr, hipGetErrorString(_s));                \
+      fflush(stderr);                                                                        \
+      if (_s != hipSuccess) return wg_set_error(WG_ERR_HIP, hipGetErrorString(_s));          \
+    }                                                                                        \
+  } while (0)
+
+bool dbg_sync() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WG_DEBUG_SYNC"); v = e && *e == '1'; }
+  return v == 1;
+}
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+bool is_early(const wg_config& c, int k) { return k % c.n_early_every == 0 && k > 0; }
+
+struct TrainWs {
+  // fp16 planes (elements)
+  _Float16 *X, *T, *S, *A;      // [FL] x C/64 chunks each (plane_c elements per fl)
+  _Float16 *GP;                 // [FL] x 2C/64 chunks, contiguous: the K operand of the cond_layer dgrad
+  _Float16 *GX0, *GX1, *GO, *SP, *MELP, *GSP;
+  float *Zpost, *OUT;           // [n_flows][B*L*8]
+  float *GZ;                    // [B*L*8]
+  float *slab;                  // wgrad phase slabs
+  float *part;                  // column-sum / row-kernel partials
+  size_t plane_c;               // elements of one C-channel plane set
+  size_t rows8;                 // B*L*8
+  size_t zero_bytes;            // prefix that `fresh` clears (all planes)
+  size_t bytes;
+};
+
+TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
+  TrainWs w;
+  const int C = c.n_channels, FL = c.n_flows * c.n_layers, M8 = c.n_mel_channels * 8;
+  const size_t chunk = (size_t)g.R * 64;           // elements of one 64-channel plane
+  w.plane_c = (size_t)(C / 64) * chunk;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes); return p; };
+  w.X = (_Float16*)take((size_t)FL * w.plane_c * 2);
+  w.T = (_Float16*)take((size_t)FL * w.plane_c * 2);
+  w.S = (_Float16*)take((size_t)FL * w.plane_c * 2);
+  w.A = (_Float16*)take((size_t)FL * w.plane_c * 2);
+  w.GP = (_Float16*)take((size_t)FL * 2 * w.plane_c * 2);
+  w.GX0 = (_Float16*)take(w.plane_c * 2);
+  w.GX1 = (_Float16*)take(w.plane_c * 2);
+  w.GO = (_Float16*)take(chunk * 2);
+  w.SP = (_Float16*)take((size_t)(M8 / 64) * chunk * 2);
+  w.MELP = (_Float16*)take(2 * chunk * 2);
+  w.GSP = (_Float16*)take((size_t)(M8 / 64) * chunk * 2);
+  w.zero_bytes = off;
+  w.rows8 = (size_t)g.B * g.L * 8;
+  w.Zpost = (float*)take((size_t)c.n_flows * w.rows8 * 4);
+  w.OUT = (float*)take((size_t)c.n_flows * w.rows8 * 4);
+  w.GZ = (float*)take(w.rows8 * 4);
+  const size_t K1 = 3 * (size_t)C + M8;
+  w.slab = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
+  size_t part = (size_t)colsum_slabs(g) * max_sz(2 * (size_t)C, (size_t)M8);
+  part = max_sz(part, (size_t)flow_bwd_workgroups(g) * 64);
+  part = max_sz(part, (size_t)start_wgrad_workgroups(g) * 5 * C);
+  w.part = (float*)take(part * 4);
+  w.bytes = off;
+  return w;
+}
+
+struct Ctx {
+  const wg_config* c;
+  const int* ck;
+  RowGeom g;
+  TrainWs w;
+  int C, FL, M8, K1, nl;
+};
+
+int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* workspace, size_t workspace_bytes, Ctx& x) {
+  if (!h) return wg_set_error(WG_ERR_INVALID, "null handle");
+  x.c = wg_internal_config(h);
+  x.ck = wg_internal_flow_channels(h);
+  const wg_config& c = *x.c;
+  if (B < 1 || n_frames < 1 || audio_len < c.n_group || audio_len % c.n_group)
+    return wg_set_error(WG_ERR_INVALID, "audio_len must be a positive multiple of n_group");
+  if ((int64_t)(n_frames - 1) * c.upsample_stride + c.upsample_kernel < audio_len)    // model.py:187
+    return wg_set_error(WG_ERR_INVALID, "upsampled mel shorter than audio");
+  const int L = audio_len / c.n_group;
+  x.g = wg_internal_geom(h, B, L, n_frames);
+  x.w = carve(c, x.g, (char*)workspace);
+  if (workspace && x.w.bytes > workspace_bytes) return wg_set_error(WG_ERR_WORKSPACE, "training workspace too small");
+  if ((size_t)x.g.R * 128 >= (1ull << 32)) return wg_set_error(WG_ERR_INVALID, "plane too large for 32-bit offsets");
+  x.C = c.n_channels;
+  x.nl = c.n_layers;
+  x.FL = c.n_flows * c.n_layers;
+  x.M8 = c.n_mel_channels * 8;
+  x.K1 = 3 * x.C + x.M8;
+  return WG_OK;
+}
+
+PRun run_of(const _Float16* base, int n_chunks, int dt) {
+  PRun r;
+  r.base = base;
+  r.n_chunks = n_chunks;
+  r.dt = dt;
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
+  Ctx x;
+  if (setup(const_cast<wg_handle*>(h), B, n_frames, audio_len, nullptr, 0, x) != WG_OK) return 0;
+  return x.w.bytes;
+}
+
+int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, const void* audio, float* z,
+                     float* const* log_s, int32_t B, int32_t n_frames, int32_t audio_len, int32_t fresh,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (!wt || !mel || !audio || !z || !log_s || !workspace) return wg_set_error(WG_ERR_INVALID, "null argument");
+  Ctx x;
+  int rc = setup(h, B, n_frames, audio_len, workspace, workspace_bytes, x);
+  if (rc) return rc;
+  const wg_config& c = *x.c;
+  const RowGeom& g = x.g;
+  TrainWs& w = x.w;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = x.C, nl = x.nl, M8 = x.M8, K1 = x.K1;
+  const int cc = C / 64, mc = M8 / 64;
+  const _Float16* w1 = (const _Float16*)wt->w1;
+  const _Float16* w2 = (const _Float16*)wt->w2;
+  const _Float16* wes = (const _Float16*)wt->wes;
+
+  if (fresh) TR_TRY(hipMemsetAsync(workspace, 0, w.zero_bytes, s));
+  TR_TRY(launch_mel_plane(mel, 0, c.n_mel_channels, g, w.MELP, s));
+  {
+    // upsample (ConvTranspose1d 1024/256, model.py:145-150, :186-189) + squeeze (:191-193): one matrix per phase
+    PGemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_runs = 4;
+    for (int j = 0; j < 4; ++j) a.run[j] = run_of(w.MELP, 2, -32 * j);
+    a.A = (const _Float16*)wt->wup;
+    a.a_phase_stride = (long long)M8 * 512;
+    a.ktot = 512;
+    a.lda = 512;
+    a.M = M8;
+    a.bias = wt->bup;
+    a.g = g;
+    a.o0 = w.SP;
+    TR_TRY(launch_plane_gemm(a, EPI_STORE16, s));
+  }
+  int z_ch = 0;
+  for (int k = 0; k <= c.n_flows; ++k) {
+    FlowArgs f;
+    memset(&f, 0, sizeof f);
+    f.direction = 1;
+    f.g = g;
+    f.C = C;
+    f.io_f16 = 0;
+    f.z_out = z;
+    f.z_out_ch0 = z_ch;
+    f.first = (k == 0);
+    f.last = (k == c.n_flows);
+    if (f.first) {
+      f.audio_in = audio;
+      f.c_in = c.n_group;
+    } else {
+      f.Z = w.Zpost + (size_t)(k - 1) * w.rows8;
+      f.out = w.OUT + (size_t)(k - 1) * w.rows8;
+      f.c_in = x.ck[k - 1];
+      f.h_in = f.c_in / 2;
+      f.log_s_out = log_s[k - 1];
+      if (!f.log_s_out) return wg_set_error(WG_ERR_INVALID, "null log_s entry");
+    }
+    if (!f.last) {
+      f.Z_w = w.Zpost + (size_t)k * w.rows8;
+      f.out_w = w.OUT + (size_t)k * w.rows8;
+      f.n_peel = is_early(c, k) ? c.n_early_size : 0;
+      f.c_next = x.ck[k];
+      f.h_next = f.c_next / 2;
+      if (f.c_in - f.n_peel != f.c_next) return wg_set_error(WG_ERR_STATE, "flow bookkeeping error");
+      f.winv = wt->w1x1[k];
+      f.wstart = wt->wstart[k];
+      f.bstart = wt->bstart[k];
+      f.out_init = wt->out_init[k];
+      f.x = w.X + (size_t)(k * nl) * w.plane_c;
+      z_ch += f.n_peel;
+    }
+    TR_TRY(launch_flow(f, s));
+    if (f.last) break;
+    for (int i = 0; i < nl; ++i) {
+      const int fl = k * nl + i, d = 1 << i;
+      const _Float16* Xi = w.X + (size_t)fl * w.plane_c;
+      _Float16* Ai = w.A + (size_t)fl * w.plane_c;
+      {
+        PGemmArgs a;   // in_layers[i] + cond_layer slice + gate (model.py:123-129)
+        memset(&a, 0, sizeof a);
+        a.n_runs = 4;
+        a.run[0] = run_of(Xi, cc, -d);
+        a.run[1] = run_of(Xi, cc, 0);
+        a.run[2] = run_of(Xi, cc, d);
+        a.run[3] = run_of(w.SP, mc, 0);
+        a.A = w1 + (size_t)fl * 2 * C * K1;
+        a.ktot = K1;
+        a.lda = K1;
+        a.M = C;
+        a.bias = wt->b1 + (size_t)fl * 2 * C;
+        a.g = g;
+        a.o0 = w.T + (size_t)fl * w.plane_c;
+        a.o1 = w.S + (size_t)fl * w.plane_c;
+        a.o2 = Ai;
+        TR_TRY(launch_plane_gemm(a, EPI_GATE, s));
+      }
+      if (i < nl - 1) {
+        PGemmArgs a;   // res half of res_skip_layers[i] + residual add (model.py:130-134)
+        memset(&a, 0, sizeof a);
+        a.n_runs = 1;
+        a.run[0] = run_of(Ai, cc, 0);
+        a.A = w2 + (size_t)fl * C * C;
+        a.ktot = C;
+        a.lda = C;
+        a.M = C;
+        a.bias = wt->b2 + (size_t)fl * C;
+        a.g = g;
+        a.i0 = Xi;
+        a.o0 = w.X + (size_t)(fl + 1) * w.plane_c;
+        TR_TRY(launch_plane_gemm(a, EPI_RES, s));
+      }
+      {
+        PGemmArgs a;   // skip half folded with WN.end (model.py:135-137): OUT += (W_end W_skip_i) acts
+        memset(&a, 0, sizeof a);
+        a.n_runs = 1;
+        a.run[0] = run_of(Ai, cc, 0);
+        a.A = wes + (size_t)fl * 32 * C;
+        a.ktot = C;
+        a.lda = C;
+        a.M = 32;
+        a.g = g;
+        a.rows32 = w.OUT + (size_t)k * w.rows8;
+        TR_TRY(launch_plane_gemm(a, EPI_ES, s));
+      }
+    }
+  }
+  return WG_OK;
+}
+
+int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_grads* gr, const float* g_z,
+                      const float* const* g_log_s, float scale, const void* audio, int32_t B, int32_t n_frames,
+                      int32_t audio_len, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!wt || !gr || !audio || !workspace) return wg_set_error(WG_ERR_INVALID, "null argument");
+  if (!(scale > 0.f)) return wg_set_error(WG_ERR_INVALID, "scale must be positive");
+  Ctx x;
+  int rc = setup(h, B, n_frames, audio_len, workspace, workspace_bytes, x);
+  if (rc) return rc;
+  const wg_config& c = *x.c;
+  const RowGeom& g = x.g;
+  TrainWs& w = x.w;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = x.C, nl = x.nl, M8 = x.M8, K1 = x.K1, FL = x.FL;
+  const int cc = C / 64, mc = M8 / 64;
+  const float inv = 1.0f / scale;
+  const _Float16* wat = (const _Float16*)wt->wat;
+  const _Float16* wbt = (const _Float16*)wt->wbt;
+  const int n_cs = colsum_slabs(g);
+
+  // channel offsets of the peeled outputs in z (model.py:201-203, :220)
+  int z_final_ch0 = 0;
+  for (int k = 0; k < c.n_flows; ++k)
+    if (is_early(c, k)) z_final_ch0 += c.n_early_size;
+
+  for (int k = c.n_flows - 1; k >= 0; --k) {
+    const int ck = x.ck[k], hk = ck / 2;
+    FlowBwdArgs fb;
+    memset(&fb, 0, sizeof fb);
+    fb.g = g;
+    fb.C = C;
+    fb.c = ck;
+    fb.h = hk;
+    fb.scale = scale;
+    fb.Zpost = w.Zpost + (size_t)k * w.rows8;
+    fb.OUT = w.OUT + (size_t)k * w.rows8;
+    fb.g_z = g_z;
+    fb.g_log_s = g_log_s ? g_log_s[k] : nullptr;
+    fb.from_z = (k == c.n_flows - 1);
+    fb.z_ch0 = z_final_ch0;
+    fb.GZ = w.GZ;
+    fb.GO = w.GO;
+    TR_TRY(launch_flow_bwd_pre(fb, s));
+    // d out_init = sum over columns of (d b | d log_s)
+    TR_TRY(launch_colsum(w.GO, 1, g, w.part, s));
+    TR_TRY(launch_slab_reduce(w.part, n_cs, 64, 8, inv, gr->dout_init[k], s));
+
+    _Float16 *gx = nullptr, *gx_next = w.GX0;   // gx = d x_{i+1} (null: zero, the last layer has no res output)
+    for (int i = nl - 1; i >= 0; --i) {
+      const int fl = k * nl + i, d = 1 << i;
+      const _Float16* Xi = w.X + (size_t)fl * w.plane_c;
+      const _Float16* Ai = w.A + (size_t)fl * w.plane_c;
+      _Float16* GPi = w.GP + (size_t)fl * 2 * w.plane_c;
+      {
+        PGemmArgs a;   // d acts = W_res^T d x_{i+1} + (W_end W_skip_i)^T d out ; gate derivative -> d pre
+        memset(&a, 0, sizeof a);
+        const _Float16* Am = wat + (size_t)fl * C * (C + 64);
+        if (gx) {
+          a.n_runs = 2;
+          a.run[0] = run_of(gx, cc, 0);
+          a.run[1] = run_of(w.GO, 1, 0);
+          a.A = Am;
+          a.ktot = C + 64;
+        } else {
+          a.n_runs = 1;
+          a.run[0] = run_of(w.GO, 1, 0);
+          a.A = Am + C;
+          a.ktot = 64;
+        }
+        a.lda = C + 64;
+        a.M = C;
+        a.g = g;
+        a.i0 = w.T + (size_t)fl * w.plane_c;
+        a.i1 = w.S + (size_t)fl * w.plane_c;
+        a.o0 = GPi;
+        TR_TRY(launch_plane_gemm(a, EPI_DGATE, s));
+      }
+      {
+        WgradArgs a;   // d W1 = d pre x [x taps | spect]^T, d b1
+        memset(&a, 0, sizeof a);
+        a.G = GPi;
+        a.m_chunks = 2 * cc;
+        a.n_runs = 4;
+        a.run[0] = run_of(Xi, cc, -d);
+        a.run[1] = run_of(Xi, cc, 0);
+        a.run[2] = run_of(Xi, cc, d);
+        a.run[3] = run_of(w.SP, mc, 0);
+        a.k_chunks = 3 * cc + mc;
+        a.g = g;
+        a.out = w.slab;
+        a.out_scale = 1.0f;
+        TR_TRY(launch_wgrad(a, s));
+        const size_t n = (size_t)2 * C * K1;
+        TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + (size_t)fl * n, s));
+        TR_TRY(launch_colsum(GPi, 2 * cc, g, w.part, s));
+        TR_TRY(launch_slab_reduce(w.part, n_cs, 2 * C, 2 * C, inv, gr->db1 + (size_t)fl * 2 * C, s));
+      }
+      if (gx) {
+        WgradArgs a;   // d W2 = d x_{i+1} x acts^T, d b2
+        memset(&a, 0, sizeof a);
+        a.G = gx;
+        a.m_chunks = cc;
+        a.n_runs = 1;
+        a.run[0] = run_of(Ai, cc, 0);
+        a.k_chunks = cc;
+        a.g = g;
+        a.out = w.slab;
+        a.out_scale = 1.0f;
+        TR_TRY(launch_wgrad(a, s));
+        const size_t n = (size_t)C * C;
+        TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw2 + (size_t)fl * n, s));
+        TR_TRY(launch_colsum(gx, cc, g, w.part, s));
+        TR_TRY(launch_slab_reduce(w.part, n_cs, C, C, inv, gr->db2 + (size_t)fl * C, s));
+      }
+      {
+        WgradArgs a;   // d (W_end W_skip_i) = d out x acts^T
+        memset(&a, 0, sizeof a);
+        a.G = w.GO;
+        a.m_chunks = 1;
+        a.n_runs = 1;
+        a.run[0] = run_of(Ai, cc, 0);
+        a.k_chunks = cc;
+        a.g = g;
+        a.out = w.slab;
+        a.out_scale = 1.0f;
+        TR_TRY(launch_wgrad(a, s));
+        TR_TRY(launch_slab_reduce(w.slab, kPhases, (size_t)64 * C, (size_t)8 * C, inv, gr->dwes + (size_t)fl * 8 * C, s));
+      }
+      {
+        PGemmArgs a;   // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)
+        memset(&a, 0, sizeof a);
+        a.n_runs = 3;
+        a.run[0] = run_of(GPi, 2 * cc, d);
+        a.run[1] = run_of(GPi, 2 * cc, 0);
+        a.run[2] = run_of(GPi, 2 * cc, -d);
+        a.A = wbt + (size_t)fl * C * 6 * C;
+        a.ktot = 6 * C;
+        a.lda = 6 * C;
+        a.M = C;
+        a.g = g;
+        a.i0 = gx;
+        a.o0 = gx_next;
+        TR_TRY(launch_plane_gemm(a, EPI_RES, s));
+        gx = gx_next;
+        gx_next = (gx == w.GX0) ? w.GX1 : w.GX0;
+      }
+    }
+    {
+      StartWgradArgs a;
+      a.g = g;
+      a.C = C;
+      a.h = hk;
+      a.GX = gx;
+      a.Zpost = fb.Zpost;
+      a.partial = w.part;
+      TR_TRY(launch_start_wgrad(a, s));
+      TR_TRY(launch_slab_reduce(w.part, start_wgrad_workgroups(g), (size_t)5 * C, (size_t)5 * C, inv, gr->dstart[k], s));
+    }
+    fb.GX = gx;
+    fb.wstart = wt->wstart[k];
+    fb.w1x1 = wt->w1x1[k];
+    if (k > 0) {
+      fb.Zprev = w.Zpost + (size_t)(k - 1) * w.rows8;
+      fb.OUTprev = w.OUT + (size_t)(k - 1) * w.rows8;
+      fb.h_prev = x.ck[k - 1] / 2;
+      fb.n_peel = is_early(c, k) ? c.n_early_size : 0;
+      if (fb.n_peel) z_final_ch0 -= fb.n_peel;
+      fb.z_peel_ch0 = z_final_ch0;
+    } else {
+      fb.audio = (const float*)audio;
+    }
+    fb.dw_partial = w.part;
+    TR_TRY(launch_flow_bwd_post(fb, s));
+    TR_TRY(launch_slab_reduce(w.part, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], s));
+  }
+  {
+    // d spect = sum over every layer of cond_layer^T d pre: ONE GEMM with K = FL*2C over the kept d pre planes
+    PGemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_runs = 1;
+    a.run[0] = run_of(w.GP, FL * 2 * cc, 0);
+    a.A = (const _Float16*)wt->wct;
+    a.ktot = FL * 2 * C;
+    a.lda = FL * 2 * C;
+    a.M = M8;
+    a.g = g;
+    a.o0 = w.GSP;
+    TR_TRY(launch_plane_gemm(a, EPI_STORE16, s));
+  }
+  {
+    WgradArgs a;   // d upsample: per phase, d spect x mel frames q..q-3 (no sum over phases)
+    memset(&a, 0, sizeof a);
+    a.G = w.GSP;
+    a.m_chunks = mc;
+    a.n_runs = 4;
+    for (int j = 0; j < 4; ++j) a.run[j] = run_of(w.MELP, 2, -32 * j);
+    a.k_chunks = 8;
+    a.g = g;
+    a.out = gr->dwup;
+    a.out_scale = inv;
+    TR_TRY(launch_wgrad(a, s));
+    TR_TRY(launch_colsum(w.GSP, mc, g, w.part, s));
+    TR_TRY(launch_slab_reduce(w.part, n_cs, M8, M8, inv, gr->dbup, s));
+  }
+  return WG_OK;
+}
+
+}  // extern "C"

@@ -108,6 +108,8 @@ struct FlowArgs {
   // ---- buffers
   float* Z;                 // [B*L][8] fp32 flow state (channels-last)
   float* out;               // [B*L][8] fp32  b | log_s of the flow just computed, re-initialised for next
+  float* Z_w;               // where the new state / re-initialised out are written: = Z / out for inference (in place);
+  float* out_w;             // the training forward keeps every flow's state and gives each flow its own buffers
   _Float16* x;              // [C/64][R][64] start output
   void* audio_out;          // infer+last: [B][8L] io dtype
   RowGeom g;

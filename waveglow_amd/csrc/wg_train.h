@@ -1,0 +1,113 @@
+// Training direction (WaveGlow.forward + backward, src/waveglow/model.py:178-221 under autograd; train.py:190-199):
+// kernel argument blocks shared by train.hip and train_api.cpp.  gfx950 only.
+//
+// Everything here works on the same fp16 planes as the inference path (wg_common.h: RowGeom, phase-major rows,
+// position-major channels inside every 32-block).  Unlike inference, weights change every optimiser step, so no
+// weight is pre-packed on the host: every matrix arrives as a plain row-major fp16 device buffer [rows][K] in
+// "(pos,pos)" order (rows and K columns permuted by chan_to_pos inside 32-blocks, done by the caller), and the
+// cond_layer o upsample fold is NOT used (it would have to be rebuilt every step) -- the upsampled, squeezed
+// spectrogram exists as planes and cond_layer is a K-segment of GEMM 1.
+#pragma once
+#include "wg_common.h"
+
+namespace wg {
+
+// One run of K-chunks of a plane-GEMM's B operand: n_chunks consecutive 64-channel planes starting at `base`
+// (chunk stride = R*64 elements), read at time offset dt (group-timesteps; phase-major rows make that a phase
+// change plus a frame shift, see RowGeom).  dt = -d / 0 / +d for the dilated taps, -32j for mel tap j.
+struct PRun {
+  const _Float16* base;
+  int n_chunks;
+  int dt;
+};
+constexpr int kMaxRuns = 4;
+
+enum PEpi : int {
+  EPI_STORE16 = 0,   // o0 = acc (+ bias)                                  spect planes, g_spect planes
+  EPI_GATE = 1,      // T = tanh(u), S = sigmoid(v), acts = T*S            model.py:13-20 (fp16 planes o0, o1, o2)
+  EPI_RES = 2,       // o0 = acc (+ bias) (+ i0)                           residual add model.py:131-134 / dgrad add
+  EPI_ES = 3,        // rows32[row][0..7] += acc rows (hi + lo)            folded end x skip (wg_common.h, api.cpp)
+  EPI_DGATE = 4,     // g_pre = g_acts * d(tanh*sigmoid)                   o0 = [2C] planes; i0 = T, i1 = S
+};
+
+// D[M x columns] = A[M x K] . B[K x columns]  for every 128-row tile of every phase.
+struct PGemmArgs {
+  PRun run[kMaxRuns];
+  int n_runs;
+  const _Float16* A;        // [M_rows][ktot] fp16 row-major, (pos,pos) order
+  long long a_phase_stride; // elements added to A per phase (upsample: one matrix per phase), else 0
+  int ktot;                 // sum of n_chunks * 64
+  int lda;                  // row stride of A in elements (>= ktot; A may point at a column offset)
+  int M;                    // EPI_GATE: C (rows per gate half, matrix has 2C rows); else number of matrix rows
+  const float* bias;        // fp32, pos order, or null
+  RowGeom g;
+  _Float16 *o0, *o1, *o2;   // output planes
+  const _Float16 *i0, *i1;  // epilogue input planes
+  float* rows32;            // EPI_ES: OUT [B*L][8]
+};
+
+// dW[m][k'] = sum over the rows of one phase of G[row][m] * X[row(+shift)][k']  -> out[phase][m][k'] * out_scale
+struct WgradArgs {
+  const _Float16* G;        // planes [m_chunks][R][64]
+  int m_chunks;
+  PRun run[kMaxRuns];       // the X operand (same runs as the forward GEMM's B operand)
+  int n_runs;
+  int k_chunks;             // sum n_chunks
+  RowGeom g;
+  float* out;               // [32 phases][m_chunks*64][k_chunks*64] fp32
+  float out_scale;
+};
+
+// Row kernels of the flow backward (coupling, 1x1, start): model.py:200-218 differentiated.
+struct FlowBwdArgs {
+  RowGeom g;
+  int C, c, h;              // WN channels, flow channels c_k, h_k = c_k/2
+  float scale;              // loss scale applied to the incoming gradients
+  // saved forward state
+  const float* Zpost;       // [B*L][8]  W.z of this flow (a0 | a1)
+  const float* OUT;         // [B*L][8]  (b | log_s) of this flow
+  // incoming gradients
+  const float* g_z;         // [B][8][L] gradient of the returned z (model.py:220-221), or null
+  const float* g_log_s;     // [B][h][L] gradient of the returned log_s of this flow, or null
+  int from_z;               // pre: 1 -> the flow output's gradient comes from g_z channels [z_ch0, z_ch0+c)
+  int z_ch0;
+  float* GZ;                // [B*L][8] fp32: pre: in = d(flow output), out = (d a0 direct | d a1)
+                            //                post: in = that, out = d(previous flow's output)
+  _Float16* GO;             // pre: fp16 plane (1 chunk): ch [0,h) = d b, [h,2h) = d log_s, rest 0
+  // post
+  const _Float16* GX;       // d x_0 planes [C/64][R][64]
+  const float* wstart;      // [C][h] pos rows
+  const float* w1x1;        // [c][c] row-major W of this flow (model.py:64)
+  const float* Zprev;       // Zpost of flow k-1 (or null when k == 0)
+  const float* OUTprev;     // OUT of flow k-1
+  int h_prev;               // h of flow k-1
+  int n_peel;               // channels peeled before this flow (model.py:201-203)
+  int z_peel_ch0;           // their channel offset in z
+  const float* audio;       // k == 0: the input audio [B][8L] fp32
+  float* dw_partial;        // [n_workgroups][64]: per-workgroup partial of d W[r][cc]
+};
+
+struct StartWgradArgs {
+  RowGeom g;
+  int C, h;
+  const _Float16* GX;       // d x_0 planes
+  const float* Zpost;       // a0 = Zpost[:, :h]
+  float* partial;           // [n_workgroups][5][C]: j < 4: d Wstart[:, j], j = 4: d bstart
+};
+
+hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s);
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+// out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
+hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
+                              hipStream_t s);
+// per-channel sum over all rows of fp16 planes -> partial [32 * Rp/128][n_chunks*64]
+hipError_t launch_colsum(const _Float16* planes, int n_chunks, const RowGeom& g, float* partial, hipStream_t s);
+int colsum_slabs(const RowGeom& g);
+hipError_t launch_mel_plane(const void* mel, int io_f16, int M, const RowGeom& g, _Float16* melp, hipStream_t s);
+hipError_t launch_flow_bwd_pre(const FlowBwdArgs& a, hipStream_t s);
+hipError_t launch_flow_bwd_post(const FlowBwdArgs& a, hipStream_t s);
+int flow_bwd_workgroups(const RowGeom& g);
+hipError_t launch_start_wgrad(const StartWgradArgs& a, hipStream_t s);
+int start_wgrad_workgroups(const RowGeom& g);
+
+}  // namespace wg

@@ -79,6 +79,7 @@ class _Engine:
     self.device = device
     self.signature: Optional[tuple] = None
     self._ws: Dict[Tuple[str, int, int, int], torch.Tensor] = {}
+    self._train_ws: Optional[Tuple[Tuple[int, int, int], torch.Tensor]] = None
 
   def __del__(self):
     try:
@@ -106,6 +107,17 @@ class _Engine:
       ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
       self._ws[k] = ws
     return ws
+
+
+  def train_workspace(self, nbytes: int, key: Tuple[int, int, int]) -> Tuple[torch.Tensor, bool]:
+    """Workspace of the training direction (saved activations); ``fresh`` tells the library to clear it: its guard
+    rows must read as zero and stay so, which holds as long as the geometry ``key`` does not change."""
+    if self._train_ws is not None and self._train_ws[0] == key and self._train_ws[1].numel() >= nbytes:
+      return self._train_ws[1], False
+    self._train_ws = None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+    self._train_ws = (key, ws)
+    return ws, True
 
 
 class WaveGlow(nn.Module):
@@ -152,12 +164,23 @@ class WaveGlow(nn.Module):
   def _weights_signature(self) -> tuple:
     return tuple((id(p), p._version, p.data_ptr()) for p in self.parameters())
 
-  def _get_engine(self, device: torch.device) -> _Engine:
+  def flow_channels(self) -> List[int]:
+    """Remaining channels c_k of every flow (model.py:160-176)."""
+    out, c = [], self.n_group
+    for k in range(self.n_flows):
+      if k % self.n_early_every == 0 and k > 0:
+        c -= self.n_early_size
+      out.append(c)
+    return out
+
+  def _get_engine(self, device: torch.device, need_weights: bool = True) -> _Engine:
     if device.type != "cuda":
       raise _lib.WgError("waveglow_amd runs on MI355X only: move the model and inputs to a 'cuda' (ROCm) device; "
                          "there is no CPU fallback")
     if self._engine is None or self._engine.device != device:
       self._engine = _Engine(self._hp, device)
+    if not need_weights:     # training direction: weights are handed over per call (waveglow_amd/train.py)
+      return self._engine
     sig = self._weights_signature()
     if self._engine.signature != sig:
       # W^-1 and every packed layout are derived state keyed on the parameter versions
@@ -212,8 +235,12 @@ class WaveGlow(nn.Module):
 
   def forward(self, forward_input):
     """model.py:178-221: (mel [B,M,F], audio [B,S]) -> (z [B,8,L], [log_s_k], [log_det_W_k]).
-    Normalising direction without autograd (the backward pass is not part of this round)."""
+    With grad mode on and trainable parameters this is the training direction (waveglow_amd/train.py: saved
+    activations, ``loss.backward()`` runs the library's backward pass); otherwise the lighter inference-only pass."""
     spect, audio = forward_input
+    if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+      from .train import train_forward
+      return train_forward(self, spect, audio)
     eng = self._get_engine(spect.device)
     io = self._io_dtype(spect)
     assert audio.dtype == spect.dtype and audio.device == spect.device
@@ -257,9 +284,41 @@ class WaveGlow(nn.Module):
     return model
 
 
+class _LossFn(torch.autograd.Function):
+  """Value from ``wg_loss``; gradient analytically: d/dz = z/(sigma^2 N), d/dlog_s = -1/N, d/dlog_det_W = -1/N."""
+
+  @staticmethod
+  def forward(ctx, sigma, n_ls, z, *rest):
+    log_s, log_det = rest[:n_ls], rest[n_ls:]
+    lib = _lib.load()
+    z32 = z.float().contiguous()
+    ls32 = [t.float().contiguous() for t in log_s]
+    ld = (C.c_float * n_ls)(*[float(x) for x in log_det])
+    ptrs = (C.c_void_p * n_ls)(*[t.data_ptr() for t in ls32])
+    sizes = (C.c_int64 * n_ls)(*[t.numel() for t in ls32])
+    out = torch.empty((), dtype=torch.float32, device=z.device)
+    ws = torch.empty(16, dtype=torch.uint8, device=z.device)
+    stream = torch.cuda.current_stream(z.device).cuda_stream
+    _lib.check(lib.wg_loss(z32.data_ptr(), z32.numel(), ptrs, sizes, n_ls, ld, float(sigma), out.data_ptr(),
+                           ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+    ctx.save_for_backward(z)
+    ctx.sigma, ctx.n_ls = float(sigma), n_ls
+    ctx.meta = [(t.shape, t.dtype) for t in log_s] + [(t.shape, t.dtype) for t in log_det]
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    (z,) = ctx.saved_tensors
+    n = z.numel()
+    gz = z * (g / (ctx.sigma * ctx.sigma * n)).to(z.dtype)
+    rest = [(-g / n).to(dt).expand(shape) for shape, dt in ctx.meta]
+    return (None, None, gz, *rest)
+
+
 class WaveGlowLoss(nn.Module):
   """src/waveglow/train.py:26-45: NLL of the flow, computed by the HIP library (``wg_loss``) on the tuple that
-  ``WaveGlow.forward`` returns.  ``y`` is ignored, as in the reference (train.py:31-32).  No autograd."""
+  ``WaveGlow.forward`` returns.  ``y`` is ignored, as in the reference (train.py:31-32).  Differentiable: the
+  gradient w.r.t. z / log_s / log_det_W is closed-form and feeds the library's backward pass."""
 
   def __init__(self, sigma: float = 1.0):
     super().__init__()
@@ -269,16 +328,5 @@ class WaveGlowLoss(nn.Module):
     z, log_s_list, log_det_W_list = y_pred
     if z.device.type != "cuda":
       raise _lib.WgError("WaveGlowLoss runs on the GPU library only")
-    lib = _lib.load()
-    z32 = z.float().contiguous()
-    ls32 = [t.float().contiguous() for t in log_s_list]
-    n = len(ls32)
-    ld = (C.c_float * n)(*[float(x) for x in log_det_W_list])
-    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ls32])
-    sizes = (C.c_int64 * n)(*[t.numel() for t in ls32])
-    out = torch.empty((), dtype=torch.float32, device=z.device)
-    ws = torch.empty(16, dtype=torch.uint8, device=z.device)
-    stream = torch.cuda.current_stream(z.device).cuda_stream
-    _lib.check(lib.wg_loss(z32.data_ptr(), z32.numel(), ptrs, sizes, n, ld, float(self.sigma), out.data_ptr(),
-                           ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
-    return out
+    log_det = [t if torch.is_tensor(t) else torch.tensor(float(t), device=z.device) for t in log_det_W_list]
+    return _LossFn.apply(self.sigma, len(log_s_list), z, *log_s_list, *log_det)

@@ -1,0 +1,202 @@
+"""Training direction: ``WaveGlow.forward`` under autograd on the HIP library (``wg_train_forward`` / ``wg_train_backward``).
+
+Reference: src/waveglow/model.py:178-221 (forward), train.py:190-199 (``loss.backward()``; Adam step on the
+weight-normed parameters).  Division of labour:
+
+* torch (differentiable plumbing, a few dozen small ops per step): evaluates the weight-norm parametrizations,
+  stacks the per-layer tensors, applies the kernels' channel-position permutation, folds ``WN.end`` into the skip
+  rows (``W_end @ W_skip_i``) and lays the upsample filter out per phase.  Because these ops are ordinary autograd
+  nodes, weight norm, the folds and the permutations are differentiated by torch itself.
+* the library: everything that touches activations -- upsample, 12 x (1x1 conv, start, 8 x (dilated conv + cond +
+  gate, res, skip/end), coupling) forward with saved fp16 activations, and the whole backward (both dgrads of every
+  layer, every weight gradient, coupling / 1x1 / start backward) -- one C call each way.
+
+There is no fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Tuple
+
+import torch
+
+from . import _lib
+
+
+def pos_perm(n: int) -> torch.Tensor:
+  """perm[P] = channel stored at position P (wg_common.h: pos_to_chan) for n channels (n % 32 == 0)."""
+  P = torch.arange(n)
+  blk, p = P // 32, P % 32
+  h, g, i = p // 16, (p // 4) % 4, p % 4
+  return blk * 32 + 8 * g + 4 * h + i
+
+
+class _Perms:
+  def __init__(self, Cc: int, M8: int, device):
+    pc = pos_perm(Cc)
+    self.c = pc.to(device)
+    self.c2 = torch.cat([pc, Cc + pc]).to(device)
+    self.m8 = pos_perm(M8).to(device)
+    self.k1 = torch.cat([pc, Cc + pc, 2 * Cc + pc, 3 * Cc + pos_perm(M8)]).to(device)
+    self.r32 = pos_perm(32).to(device)
+
+
+def pack_weights(model) -> Tuple[torch.Tensor, ...]:
+  """Differentiable packing of the module's parameters into the (pos,pos) matrices of wg_train_weights."""
+  hp = model._hp
+  Cc, nl, nf, M, M8 = hp.n_channels, hp.n_layers, model.n_flows, hp.n_mel_channels, hp.n_mel_channels * 8
+  dev = model.upsample.weight.device
+  pm = _Perms(Cc, M8, dev)
+  w_in, b_in, w_cond, b_cond, w_res, b_res, w_es, start5, out_init, w1x1 = [], [], [], [], [], [], [], [], [], []
+  for k in range(nf):
+    wn = model.WN[k]
+    h2 = wn.end.weight.shape[0]
+    w_end = wn.end.weight[:, :, 0]                                   # [2h, C]
+    cw = wn.cond_layer.weight[:, :, 0].view(nl, 2 * Cc, M8)
+    cb = wn.cond_layer.bias.view(nl, 2 * Cc)
+    b_skip_sum = 0
+    for i in range(nl):
+      w_in.append(wn.in_layers[i].weight)                            # [2C, C, 3]
+      b_in.append(wn.in_layers[i].bias + cb[i])
+      w_cond.append(cw[i])
+      rs_w = wn.res_skip_layers[i].weight[:, :, 0]
+      rs_b = wn.res_skip_layers[i].bias
+      if i < nl - 1:                                                  # model.py:131-134
+        w_res.append(rs_w[:Cc])
+        b_res.append(rs_b[:Cc])
+        w_skip, b_skip = rs_w[Cc:], rs_b[Cc:]
+      else:                                                           # model.py:135-136
+        w_res.append(torch.zeros_like(rs_w[:Cc]))
+        b_res.append(torch.zeros_like(rs_b[:Cc]))
+        w_skip, b_skip = rs_w, rs_b
+      es = w_end @ w_skip                                             # end(sum_i skip_i): [2h, C]
+      w_es.append(torch.nn.functional.pad(es, (0, 0, 0, 8 - h2)))
+      b_skip_sum = b_skip_sum + b_skip
+    out_init.append(torch.nn.functional.pad(w_end @ b_skip_sum + wn.end.bias, (0, 8 - h2)))
+    ws = wn.start.weight[:, :, 0]                                     # [C, h]
+    s5 = torch.cat([torch.nn.functional.pad(ws, (0, 4 - ws.shape[1])).t(), wn.start.bias[None, :]], 0)   # [5, C]
+    start5.append(s5[:, pm.c])
+    w = model.convinv[k].conv.weight[:, :, 0]
+    w1x1.append(torch.nn.functional.pad(w, (0, 8 - w.shape[1], 0, 8 - w.shape[0])))
+  FL = nf * nl
+  w_in = torch.stack(w_in).permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)      # K = tap-major
+  w1 = torch.cat([w_in, torch.stack(w_cond)], 2)[:, pm.c2][:, :, pm.k1]
+  b1 = torch.stack(b_in)[:, pm.c2]
+  w2 = torch.stack(w_res)[:, pm.c][:, :, pm.c]
+  b2 = torch.stack(b_res)[:, pm.c]
+  wes = torch.stack(w_es)[:, :, pm.c]                                           # [FL, 8, C]
+  up = model.upsample.weight                                                    # [M_in, M_out, 1024]
+  wup = up.view(M, M, 4, 32, 8).permute(3, 1, 4, 2, 0).reshape(32, M8, 4, M)    # [p][(o,g)][j][i]
+  wup = torch.nn.functional.pad(wup, (0, 128 - M)).reshape(32, M8, 512)[:, pm.m8]
+  bup = model.upsample.bias.repeat_interleave(8)[pm.m8]
+  return (w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous(), wes.contiguous(), wup.contiguous(),
+          bup.contiguous(), torch.stack(start5).contiguous(), torch.stack(out_init).contiguous(),
+          torch.stack(w1x1).contiguous())
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+  return C.c_void_p(t.data_ptr())
+
+
+class _Weights:
+  """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward)."""
+
+  def __init__(self, model, packed, flow_c: List[int]):
+    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = [t.detach() for t in packed]
+    hp = model._hp
+    Cc, nf = hp.n_channels, model.n_flows
+    FL = w1.shape[0]
+    dev = w1.device
+    r32 = pos_perm(32).to(dev)
+    self.w1 = w1.half()
+    self.b1, self.b2, self.bup = b1.float(), b2.float(), bup.float()
+    self.w2 = w2.half()
+    hi = wes.half()
+    lo = (wes - hi.float()).half()
+    nat = torch.cat([hi, lo, torch.zeros_like(hi), torch.zeros_like(hi)], 1)     # natural MFMA rows 0..31
+    self.wes = nat[:, r32].contiguous()                    # matrix row chan_to_pos(r) holds MFMA row r
+    self.wat = torch.cat([self.w2.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2).contiguous()
+    self.wbt = torch.cat([self.w1[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2).contiguous()
+    self.wct = self.w1[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc).contiguous()
+    self.wup = wup.half()
+    self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
+    self.bstart = [start5[k, 4].contiguous().float() for k in range(nf)]
+    self.out_init = [out_init[k].contiguous().float() for k in range(nf)]
+    self.w1x1 = [w1x1[k, :flow_c[k], :flow_c[k]].contiguous().float() for k in range(nf)]
+    arr = lambda ts: (C.c_void_p * nf)(*[t.data_ptr() for t in ts])
+    self._arrs = [arr(self.wstart), arr(self.bstart), arr(self.out_init), arr(self.w1x1)]
+    self.struct = _lib.WgTrainWeights(_ptr(self.w1), _ptr(self.b1), _ptr(self.w2), _ptr(self.b2), _ptr(self.wes),
+                                      _ptr(self.wat), _ptr(self.wbt), _ptr(self.wct), _ptr(self.wup), _ptr(self.bup),
+                                      C.cast(self._arrs[0], C.c_void_p), C.cast(self._arrs[1], C.c_void_p),
+                                      C.cast(self._arrs[2], C.c_void_p), C.cast(self._arrs[3], C.c_void_p))
+
+
+class _TrainFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, model, mel, audio, scale, *packed):
+    eng = model._get_engine(mel.device, need_weights=False)
+    lib = eng.lib
+    B, M, F_ = mel.shape
+    S = audio.shape[1]
+    L = S // model.n_group
+    flow_c = model.flow_channels()
+    wts = _Weights(model, packed, flow_c)
+    z = torch.empty((B, model.n_group, L), dtype=torch.float32, device=mel.device)
+    log_s = [torch.empty((B, c // 2, L), dtype=torch.float32, device=mel.device) for c in flow_c]
+    nbytes = lib.wg_train_workspace_bytes(eng.handle, B, F_, S)
+    if nbytes == 0:
+      raise _lib.WgError(lib.wg_last_error().decode())
+    ws, fresh = eng.train_workspace(nbytes, (B, F_, S))
+    ls = (C.c_void_p * len(log_s))(*[t.data_ptr() for t in log_s])
+    stream = torch.cuda.current_stream(mel.device).cuda_stream
+    _lib.check(lib.wg_train_forward(eng.handle, C.byref(wts.struct), _ptr(mel), _ptr(audio), _ptr(z), ls, B, F_, S,
+                                    1 if fresh else 0, _ptr(ws), ws.numel(), C.c_void_p(stream)))
+    ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio = model, wts, ws, (B, F_, S), audio
+    ctx.scale = float(scale) if scale else float(2.0 ** round(math.log2(z.numel())))
+    ctx.shapes = [t.shape for t in packed]
+    return (z, *log_s)
+
+  @staticmethod
+  def backward(ctx, g_z, *g_log_s):
+    model, wts = ctx.model, ctx.wts
+    eng = model._engine
+    lib = eng.lib
+    B, F_, S = ctx.dims
+    dev = ctx.audio.device
+    nf = model.n_flows
+    grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
+    dw1, db1, dw2, db2, dwes, dwup, dbup, dstart, dout_init, dw1x1 = grads
+    arr = lambda t: (C.c_void_p * nf)(*[t[k].data_ptr() for k in range(nf)])
+    a_start, a_init, a_1x1 = arr(dstart), arr(dout_init), arr(dw1x1)
+    gstruct = _lib.WgTrainGrads(_ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dwes), _ptr(dwup), _ptr(dbup),
+                                C.cast(a_start, C.c_void_p), C.cast(a_init, C.c_void_p), C.cast(a_1x1, C.c_void_p))
+    gz = g_z.float().contiguous() if g_z is not None else None
+    gls = [g.float().contiguous() if g is not None else None for g in g_log_s]
+    gl_arr = (C.c_void_p * nf)(*[(g.data_ptr() if g is not None else None) for g in gls])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.wg_train_backward(eng.handle, C.byref(wts.struct), C.byref(gstruct),
+                                     _ptr(gz) if gz is not None else None, gl_arr, C.c_float(ctx.scale),
+                                     _ptr(ctx.audio), B, F_, S, _ptr(ctx.ws), ctx.ws.numel(), C.c_void_p(stream)))
+    ctx.wts = None
+    return (None, None, None, None, *grads)
+
+
+def train_forward(model, mel: torch.Tensor, audio: torch.Tensor, grad_scale: float = 0.0):
+  """(z, [log_s_k], [log_det_W_k]) with an autograd graph back to the module's parameters (model.py:178-221)."""
+  if mel.device.type != "cuda":
+    raise _lib.WgError("waveglow_amd runs on MI355X only: there is no CPU fallback")
+  if mel.dtype != torch.float32 or audio.dtype != torch.float32:
+    raise _lib.WgError("the training direction takes float32 mel / audio (reference: fp32 training)")
+  B, M, F_ = mel.shape
+  S = audio.shape[1]
+  assert (F_ - 1) * 256 + 1024 >= S                    # model.py:187
+  S = S - S % model.n_group                            # unfold drops the remainder (model.py:191,195)
+  audio = audio[:, :S].contiguous()
+  mel = mel.contiguous()
+  packed = pack_weights(model)
+  out = _TrainFn.apply(model, mel, audio, grad_scale, *packed)
+  z, log_s = out[0], list(out[1:])
+  L = S // model.n_group
+  log_det = [B * L * torch.logdet(model.convinv[k].conv.weight.squeeze()) for k in range(model.n_flows)]   # model.py:63
+  return z, log_s, log_det
