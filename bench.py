@@ -96,6 +96,71 @@ def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
           "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}] (configs[0] is T=500), sigma 0.6, {best:.2f} s"}
 
 
+def bench_train(args, rank, world, dev, dist):
+  """BASELINE configs[3]: the training step of src/waveglow/train.py:190-199 (forward, WaveGlowLoss, backward, Adam),
+  data-parallel: per-GPU batch fixed (weak scaling), gradients averaged by one bucketed all-reduce per step."""
+  from waveglow_amd import synthetic
+  from waveglow_amd.distributed import GradientAllReducer
+  from waveglow_amd.hparams import HParams
+  from waveglow_amd.model import WaveGlow, WaveGlowLoss
+  hp = HParams(n_channels=args.channels)
+  model = WaveGlow(hp)
+  model.load_state_dict(synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=0)))
+  model = model.to(dev).train()
+  B = args.batch if args.batch != 16 else 32
+  S = args.segment
+  F_ = 1 + S // 256
+  mel = synthetic.make_mel(B, F_, seed=77 + rank).to(dev)
+  g = torch.Generator().manual_seed(5 + rank)
+  wav = (torch.rand(B, S, generator=g) * 0.6 - 0.3).to(dev)
+  crit = WaveGlowLoss(1.0)
+  opt = torch.optim.Adam(model.parameters(), lr=1e-4)     # train.py:58-66
+  red = GradientAllReducer(model.parameters())
+
+  def step():
+    opt.zero_grad(set_to_none=True)
+    loss = crit(model((mel, wav)), None)
+    loss.backward()
+    red.reduce()
+    opt.step()
+    return loss
+
+  for _ in range(args.warmup):
+    loss = step()
+  torch.cuda.synchronize(dev)
+  if dist is not None:
+    dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss = step()
+  torch.cuda.synchronize(dev)
+  if dist is not None:
+    dist.barrier()
+  elapsed = time.perf_counter() - t0
+  assert torch.isfinite(loss.detach()).all()
+  if dist is not None:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  if rank == 0:
+    samples = B * S * world
+    flops = 3 * 2.0 * (81235408 / 8 if args.channels == 256 else 261355984 / 8) * samples   # fwd + 2x bwd, SURVEY 8d
+    print(json.dumps({
+      "metric": "training samples/sec (WaveGlow-256 train step: forward + loss + backward + all-reduce + Adam)",
+      "value": round(samples * args.steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+      "scaling": "weak", "vs_baseline": None,
+      "dtype": "f16 MFMA operands / saved activations / gradient planes, f32 accumulate, f32 weights + Adam",
+      "data": "synthetic (random mels + uniform audio, random-init weight-normed parameters)",
+      "config": {"workload": f"configs[3]: {args.channels}ch train step, batch={B}/GPU x {S} samples, {F_} mel frames",
+                 "parallelism": f"dp{world}, bucketed gradient all-reduce (RCCL)"},
+      "loss": float(loss.detach()),
+      "algorithmic_TFLOP_per_s": round(flops * args.steps / elapsed / 1e12, 1)}), flush=True)
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +171,10 @@ def main():
   ap.add_argument("--channels", type=int, default=256)
   ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--workload", default="infer", choices=["infer", "train"],
+                  help="infer: BASELINE configs[1] (the headline metric, default); train: configs[3], one optimiser step "
+                       "(forward + loss + backward + gradient all-reduce + Adam) on batch 32 x 16000 samples per GPU")
+  ap.add_argument("--segment", type=int, default=16000)
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +193,9 @@ def main():
   from waveglow_amd import synthetic
   from waveglow_amd.hparams import HParams
   from waveglow_amd.model import WaveGlow
+
+  if args.workload == "train":
+    return bench_train(args, rank, world, dev, dist)
 
   hp = HParams(n_channels=args.channels)
   sd = synthetic.make_state_dict(hp, seed=0)
