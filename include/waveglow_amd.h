@@ -143,9 +143,12 @@ int wg_stft_denoise(wg_stft* h, const float* audio, const float* bias_mag, float
 
 /* ---- Training direction: WaveGlow.forward under autograd and loss.backward() ---------------------------------------
  * (src/waveglow/model.py:178-221, train.py:190-199).  Weights change every optimiser step, so they are NOT taken from
- * the handle: the caller passes device buffers with every matrix row-major fp16 in "(pos,pos)" order -- rows and
- * K columns permuted inside 32-blocks so that position 16h+4g+i holds channel 8g+4h+i (waveglow_amd/train.py builds
- * them with differentiable torch ops, so weight norm and the folds below are differentiated by the caller's autograd).
+ * the handle: the caller passes device buffers.  Every fp16 matrix below is given as [rows][K] in "(pos,pos)" order
+ * -- rows and K columns permuted inside 32-blocks so that position 16h+4g+i holds channel 8g+4h+i -- and then laid out
+ * in MFMA-fragment order [K/64][rows/32][4][64 lanes][8]: lane (r = lane&31, h = lane>>5), element j of sub-step s,
+ * block b, K-step t = Mat[32b + pos(r)][64t + 32h + 8s + j]  (waveglow_amd/train.py: differentiable torch ops build
+ * the (pos,pos) matrices, so weight norm and the folds below are differentiated by the caller's autograd; one gather
+ * per matrix type produces the fragment order).  Gradients come back as plain [rows][K] (pos,pos) fp32.
  * C = n_channels, M8 = 8*n_mel_channels, fl = flow*n_layers + layer, K1 = 3C + M8, h_k / c_k per flow.
  * Needs only wg_create (no wg_set_tensor / wg_finalize). */
 typedef struct wg_train_weights {

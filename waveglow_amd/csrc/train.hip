@@ -13,6 +13,8 @@
 // (the hand-scheduled inference kernel in kernels.hip is the template for tuning it).
 #include "wg_train.h"
 
+#include <type_traits>
+
 namespace wg {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -45,9 +47,11 @@ __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, in
 // plane GEMM.  Workgroup = 8 waves = one tile of 128 consecutive rows of one phase x 256 matrix rows (x 2 halves for
 // the gate); wave w owns the 32-row block (8*blockIdx.y + w).  K-step = one 64-channel plane chunk: the B tile
 // (128 rows x 128 B) goes global -> registers -> LDS (XOR-swizzled 16-byte pieces, double buffered, one barrier per
-// step); A fragments come straight from the row-major matrix: lane (r, h) reads the 64 contiguous bytes
-// A[row r][k0 + 32h ..], i.e. element j of MFMA sub-step s is k = 32h + 8s + j, and the B fragment of that sub-step
-// is LDS piece 4h + s of the lane's column -- the K order inside a step is free as long as both operands agree.
+// step); A comes in MFMA-fragment order [K-step][32-row block][sub-step s][lane][8] (wg_train.h), so a wave's load of
+// one fragment is one contiguous KiB; element j of lane (r, h) in sub-step s is k = 32h + 8s + j of the step, and the
+// B fragment of that sub-step is LDS piece 4h + s of the lane's column -- the K order inside a step is free as long
+// as both operands agree.  (Reading fragments straight from a row-major matrix -- 64 lanes on 64 different cache
+// lines per load -- ran the whole kernel at the L1's line rate: 2.5x slower.)
 // =============================================================================================
 template <int EPI>
 __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
@@ -64,10 +68,11 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   const size_t R64 = (size_t)g.R * 64;
 
   const _Float16* Ap = a.A + (size_t)p * a.a_phase_stride;
-  const int mrow = (active ? blk * 32 : 0) + pos_local(r);
+  const int ablk = active ? blk : 0;
+  const size_t a_step = (size_t)a.n_blk * 2048;      // elements per K-step: n_blk blocks x 4 sub-steps x 64 lanes x 8
   const _Float16* arow[MT];
-  arow[0] = Ap + (size_t)mrow * a.lda + 32 * h;
-  if (MT == 2) arow[MT - 1] = Ap + (size_t)(a.M + mrow) * a.lda + 32 * h;
+  arow[0] = Ap + (size_t)ablk * 2048 + lane * 8;
+  if (MT == 2) arow[MT - 1] = Ap + (size_t)(a.M / 32 + ablk) * 2048 + lane * 8;
 
   f32x16 acc[MT][4];
 #pragma unroll
@@ -84,58 +89,76 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   const int brow0 = tid >> 3, bpc = tid & 7;
   const int lds_w0 = brow0 * 64 + ((bpc ^ (brow0 & 7)) << 3);
   const int lds_w1 = (brow0 + 64) * 64 + ((bpc ^ (brow0 & 7)) << 3);   // (brow0 + 64) & 7 == brow0 & 7
-  half8 bn0, bn1, an[MT][4], ac[MT][4];
 
-  int ri = 0, ci = 0;   // run / chunk of the step being FETCHED
-  auto fetch = [&](int step) {
+  // Prefetch distance TWO K-steps (one step of MFMAs is shorter than a loaded L2/HBM round trip when all 256 CUs
+  // burst their tiles together): A fragments in a two-step register ring, every fragment refilled for step st+2
+  // right after its last MFMA of step st; B in two register stages: fetched for st+2 at the top of step st,
+  // committed to the other LDS buffer at the end of step st+1.  Waits are the compiler's (counted vmcnt); the
+  // sched_barriers pin the issue order, which is what makes the counts come out as "wait for the oldest only".
+  half8 aring[2][MT][4], bst[2][2];
+  int ri = 0, ci = 0;   // run / chunk of the next B tile to fetch (tiles are fetched in step order)
+  // (the loop body is kept branch-free: hipcc's vmcnt bookkeeping turns conservative -- vmcnt(0) -- at every
+  //  control-flow join, so past the last step the fetches simply repeat the last tile / fragment)
+  auto fetch_b = [&](half8* dst) {
     const PRun& R = a.run[ri];
     const _Float16* src = R.base + (size_t)ci * R64 + (shifted_row(g, p, R.dt) + r0) * 64;
-    bn0 = *(const half8*)(src + (size_t)brow0 * 64 + bpc * 8);
-    bn1 = *(const half8*)(src + (size_t)(brow0 + 64) * 64 + bpc * 8);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) an[mt][s] = *(const half8*)(arow[mt] + (size_t)step * 64 + 8 * s);
-    if (++ci == R.n_chunks) { ci = 0; ++ri; }
+    dst[0] = *(const half8*)(src + (size_t)brow0 * 64 + bpc * 8);
+    dst[1] = *(const half8*)(src + (size_t)(brow0 + 64) * 64 + bpc * 8);
+    const bool last_chunk = ci + 1 == R.n_chunks, last_run = ri + 1 == a.n_runs;
+    ci = last_chunk ? (last_run ? ci : 0) : ci + 1;
+    ri = (last_chunk && !last_run) ? ri + 1 : ri;
   };
-  auto commit = [&](int buf) {
-    *(half8*)&sB[buf][lds_w0] = bn0;
-    *(half8*)&sB[buf][lds_w1] = bn1;
+  auto commit_b = [&](int buf, const half8* srcr) {
+    *(half8*)&sB[buf][lds_w0] = srcr[0];
+    *(half8*)&sB[buf][lds_w1] = srcr[1];
+  };
+  auto fetch_a = [&](half8 (*dst)[4], int step) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ac[mt][s] = an[mt][s];
+      for (int s = 0; s < 4; ++s) dst[mt][s] = *(const half8*)(arow[mt] + (size_t)step * a_step + 512 * s);
   };
 
-  fetch(0);
-  commit(0);
+  const int last = n_steps - 1;
+  fetch_b(bst[0]);
+  fetch_a(aring[0], 0);
+  fetch_b(bst[1]);
+  fetch_a(aring[1], last < 1 ? last : 1);
+  commit_b(0, bst[0]);
   __syncthreads();
-  for (int st = 0; st < n_steps; ++st) {
-    const int buf = st & 1;
-    const bool more = st + 1 < n_steps;
-    half8 a_use[MT][4];
+
+  // waves without rows (M < 256 x MT) run the same instruction stream on block 0 and skip the epilogue
+  auto body = [&](auto PAR, int st) {
+    constexpr int par = decltype(PAR)::value;    // = st & 1: ring slot, B stage and LDS buffer of this step
+    const int st2 = st + 2 < last ? st + 2 : last;
+    fetch_b(bst[par]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int s = 0; s < 4; ++s) {
+      half8 bf[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) a_use[mt][s] = ac[mt][s];
-    if (more) fetch(st + 1);
-    if (active) {
+      for (int ct = 0; ct < 4; ++ct)
+        bf[ct] = *(const half8*)&sB[par][(ct * 32 + r) * 64 + (((4 * h + s) ^ (r & 7)) << 3)];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        half8 bf[4];
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          bf[ct] = *(const half8*)&sB[buf][(ct * 32 + r) * 64 + (((4 * h + s) ^ (r & 7)) << 3)];
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[par][mt][s], bf[ct], acc[mt][ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[mt][s], bf[ct], acc[mt][ct], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; ++mt)
+        aring[par][mt][s] = *(const half8*)(arow[mt] + (size_t)st2 * a_step + 512 * s);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) commit(buf ^ 1);
+    commit_b(par ^ 1, bst[par ^ 1]);
     __syncthreads();
+  };
+  int st = 0;
+  for (; st + 1 < n_steps; st += 2) {
+    body(std::integral_constant<int, 0>{}, st);
+    body(std::integral_constant<int, 1>{}, st + 1);
   }
+  if (st < n_steps) body(std::integral_constant<int, 0>{}, st);
   if (!active) return;
 
   // ---- epilogue: lane (column r of column tile ct, half h) holds matrix positions P0 .. P0+15 of its 32-block
@@ -230,43 +253,46 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
 }
 
 // =============================================================================================
-// Weight gradient.  out[phase][m][k'] = sum_rows G[row][m] X[row + shift][k'] over the Rp rows of one phase.
-// Workgroup = 4 waves = a 128 (m) x 128 (k') output tile of one phase; wave (wm, wk) owns the 64 x 64 quadrant.
-// Both operands are [row][channel] planes and the contraction runs over ROWS, so an MFMA fragment (8 consecutive
-// k = rows, one channel per lane) is a column of the LDS tile: fetched with ds_read_b64_tr_b16, which hands lane i
-// of a 16-lane group column i of a 4-row x 16-column block (cdna_hip_programming.md T10).  LDS rows are padded
-// to 320 B so that the 4 rows x 64 B a 32-lane half touches fall on 64 distinct banks.
-// Guard / invalid rows of G are zero by construction (every producer writes zeros there), so no masking.
+// Weight gradient.  out[slab][m][k'] = sum_rows G[row][m] X[row + shift][k'] over the rows of one slab (a phase, or
+// 1/row_split of a phase).  Workgroup = 8 waves = a 256 (m) x 128 (k') output tile; wave (wm, wk) owns a 64 x 64
+// quadrant.  Both operands are [row][channel] planes and the contraction runs over ROWS, so an MFMA fragment
+// (8 consecutive k = rows, one channel per lane) is a column of the LDS tile: fetched with ds_read_b64_tr_b16, which
+// hands lane i of a 16-lane group column i of a 4-row x 16-column block (cdna_hip_programming.md T10).  LDS rows are
+// padded (+64 B) so that the 4 rows x 64 B a 32-lane half touches fall on 64 distinct banks.
+// Register-staged tiles two steps ahead, branch-free loop (see plane_gemm_kernel).  Chunks past the end of an operand
+// are clamped to its last chunk: their products are computed and never stored.
+// Guard / invalid rows of G are zero by construction (every producer writes zeros there), so no row masking.
 // =============================================================================================
-constexpr int WG_RS = 160;      // LDS row stride in halves
+constexpr int WG_GS = 288;      // LDS row stride of the G tile in halves (4 chunks + pad)
+constexpr int WG_XS = 160;      // ... of the X tile (2 chunks + pad)
 constexpr int WG_STEP = 32;     // rows per step
 
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 sG[2][WG_STEP * WG_RS];
-  __shared__ __attribute__((aligned(16))) _Float16 sX[2][WG_STEP * WG_RS];
+__global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 sG[2][WG_STEP * WG_GS];
+  __shared__ __attribute__((aligned(16))) _Float16 sX[2][WG_STEP * WG_XS];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wk = w & 1;
   const RowGeom& g = a.g;
-  const int p = blockIdx.z;
-  const int mc0 = blockIdx.x * 2, kc0 = blockIdx.y * 2;
+  const int slab = blockIdx.z;
+  const int p = slab / a.row_split, rs = slab - p * a.row_split;
+  const int rows_per = g.Rp / a.row_split;
+  const int mc0 = blockIdx.x * 4, kc0 = blockIdx.y * 2;
   const size_t R64 = (size_t)g.R * 64;
 
-  // staging: thread -> 2 pieces per operand: idx = tid, tid + 256: row = idx >> 4, half e = (idx >> 3) & 1, piece = idx & 7
-  const int srow = tid >> 4, se = (tid >> 3) & 1, spc = tid & 7;
-  const _Float16* gsrc = nullptr;
-  if (mc0 + se < a.m_chunks) gsrc = a.G + (size_t)(mc0 + se) * R64 + ((size_t)kRowPad + (size_t)p * g.Rp) * 64;
-  const _Float16* xsrc = nullptr;
+  // staging.  G: pieces tid, tid + 512 of 1024: row = (tid >> 5) + 16 q, chunk e = (tid >> 3) & 3, piece = tid & 7
+  //           X: piece tid of 512: row = tid >> 4, chunk e = (tid >> 3) & 1, piece = tid & 7
+  const int grow = tid >> 5, ge = (tid >> 3) & 3, xrow = tid >> 4, xe = (tid >> 3) & 1, spc = tid & 7;
+  const int gch = (mc0 + ge < a.m_chunks) ? mc0 + ge : a.m_chunks - 1;
+  const _Float16* gsrc = a.G + (size_t)gch * R64 + ((size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + grow) * 64 + spc * 8;
+  const _Float16* xsrc;
   {
-    int c = kc0 + se;
-    for (int i = 0; i < a.n_runs; ++i) {
-      if (c < a.run[i].n_chunks) {
-        xsrc = a.run[i].base + (size_t)c * R64 + shifted_row(g, p, a.run[i].dt) * 64;
-        break;
-      }
-      c -= a.run[i].n_chunks;
-    }
+    int c = (kc0 + xe < a.k_chunks) ? kc0 + xe : a.k_chunks - 1;
+    int i = 0;
+    while (c >= a.run[i].n_chunks) { c -= a.run[i].n_chunks; ++i; }
+    xsrc = a.run[i].base + (size_t)c * R64 + (shifted_row(g, p, a.run[i].dt) + (size_t)rs * rows_per + xrow) * 64 + spc * 8;
   }
-  const int lds_w = srow * WG_RS + se * 64 + spc * 8;
+  const int lds_g = grow * WG_GS + ge * 64 + spc * 8;
+  const int lds_x = xrow * WG_XS + xe * 64 + spc * 8;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -275,67 +301,92 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[i][k][j] = 0.0f;
+  // bias gradient = row sums of G: the waves of the first k' tile also multiply their G fragments by a ones matrix
+  const bool do_bias = a.bias_out != nullptr && blockIdx.y == 0 && wk == 0;
+  f32x16 accb[2];
+  half8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accb[i][j] = 0.0f;
 
-  half8 gn[2], xn[2];
-  auto fetch = [&](int st) {
-    const size_t ro = (size_t)(st * WG_STEP + srow) * 64 + spc * 8;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      half8 z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.0f;
-      gn[q] = gsrc ? *(const half8*)(gsrc + ro + (size_t)q * 16 * 64) : z;
-      xn[q] = xsrc ? *(const half8*)(xsrc + ro + (size_t)q * 16 * 64) : z;
-    }
+  half8 gst[2][2], xst[2];
+  auto fetch = [&](int par, int st) {
+    const size_t ro = (size_t)st * WG_STEP * 64;
+    gst[par][0] = *(const half8*)(gsrc + ro);
+    gst[par][1] = *(const half8*)(gsrc + ro + 16 * 64);
+    xst[par] = *(const half8*)(xsrc + ro);
   };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      *(half8*)&sG[buf][lds_w + q * 16 * WG_RS] = gn[q];
-      *(half8*)&sX[buf][lds_w + q * 16 * WG_RS] = xn[q];
-    }
+  auto commit = [&](int buf, int par) {
+    *(half8*)&sG[buf][lds_g] = gst[par][0];
+    *(half8*)&sG[buf][lds_g + 16 * WG_GS] = gst[par][1];
+    *(half8*)&sX[buf][lds_x] = xst[par];
   };
 
   // transposing fragment read: lane = 16*g16 + u; MFMA operand lane (r = lane & 31, hh = lane >> 5) needs rows
   // 16s + 8hh + j (j < 8) of channel r: two 4-row blocks, lane (q = u >> 2, pq = u & 3) addresses row q, cols 4pq..
   const int g16 = lane >> 4, hh = g16 >> 1, hf = g16 & 1, u = lane & 15;
-  const int tr_off = (8 * hh + (u >> 2)) * WG_RS + 16 * hf + 4 * (u & 3);
-  auto frag = [&](const _Float16* tile, int col0, int s) -> half8 {
-    const _Float16* q0 = tile + tr_off + 16 * s * WG_RS + col0;
+  const int tr_row = 8 * hh + (u >> 2), tr_col = 16 * hf + 4 * (u & 3);
+  auto frag = [&](const _Float16* tile, int stride, int col0, int s) -> half8 {
+    const _Float16* q0 = tile + (tr_row + 16 * s) * stride + tr_col + col0;
     const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)q0);
-    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 4 * WG_RS));
+    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 4 * stride));
     const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
     return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
-  const int n_steps = g.Rp / WG_STEP;
-  fetch(0);
-  commit(0);
+  const int n_steps = rows_per / WG_STEP, last = n_steps - 1;
+  fetch(0, 0);
+  fetch(1, last < 1 ? last : 1);
+  commit(0, 0);
   __syncthreads();
-  for (int st = 0; st < n_steps; ++st) {
-    const int buf = st & 1;
-    const bool more = st + 1 < n_steps;
-    if (more) fetch(st + 1);
+  auto body = [&](auto PAR, int st) {
+    constexpr int par = decltype(PAR)::value;    // = st & 1: LDS buffer of this step; stage par is free again
+    fetch(par, st + 2 < last ? st + 2 : last);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < WG_STEP / 16; ++s) {
       half8 af[2], bf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[i] = frag(sG[buf], wm * 64 + 32 * i, s);
-        bf[i] = frag(sX[buf], wk * 64 + 32 * i, s);
+        af[i] = frag(sG[par], WG_GS, wm * 64 + 32 * i, s);
+        bf[i] = frag(sX[par], WG_XS, wk * 64 + 32 * i, s);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int k = 0; k < 2; ++k)
           acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[k], acc[i][k], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], ones, accb[i], 0, 0, 0);
+      }
     }
-    if (more) commit(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(par ^ 1, par ^ 1);
     __syncthreads();
+  };
+  int st = 0;
+  for (; st + 1 < n_steps; st += 2) {
+    body(std::integral_constant<int, 0>{}, st);
+    body(std::integral_constant<int, 1>{}, st + 1);
   }
+  if (st < n_steps) body(std::integral_constant<int, 0>{}, st);
 
   const int Mtot = a.m_chunks * 64, Ktot = a.k_chunks * 64;
   const int r = lane & 31, h = lane >> 5;
+  if (do_bias && r == 0) {     // every column of accb holds the row sums; column 0 writes them
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m0 = (mc0 + wm) * 64 + 32 * i;
+      if (m0 >= Mtot) continue;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        a.bias_out[(size_t)slab * Mtot + m0 + (j & 3) + 8 * (j >> 2) + 4 * h] = accb[i][j];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m0 = (mc0 + wm) * 64 + 32 * i;
@@ -347,35 +398,56 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int m = m0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-        a.out[((size_t)p * Mtot + m) * Ktot + kk] = acc[i][k][j] * a.out_scale;
+        a.out[((size_t)slab * Mtot + m) * Ktot + kk] = acc[i][k][j] * a.out_scale;
       }
     }
   }
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
-  if (a.g.Rp % WG_STEP || a.n_runs < 1 || a.n_runs > kMaxRuns) return hipErrorInvalidValue;
+  if (a.n_runs < 1 || a.n_runs > kMaxRuns || a.row_split < 1 || a.g.Rp % (a.row_split * WG_STEP)) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks;
-  if (k != a.k_chunks) return hipErrorInvalidValue;
-  dim3 grid((a.m_chunks + 1) / 2, (a.k_chunks + 1) / 2, kPhases);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, a);
+  if (k != a.k_chunks || a.m_chunks < 1) return hipErrorInvalidValue;
+  dim3 grid((a.m_chunks + 3) / 4, (a.k_chunks + 1) / 2, kPhases * a.row_split);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(512), 0, s, a);
   return hipGetLastError();
 }
 
-// out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible)
+// out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads, four
+// independent partial sums so that four slab reads are in flight per thread.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, size_t stride,
                                                           size_t n, float scale, float* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float s = 0.0f;
-    for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * stride + i];
-    out[i] = s * scale;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= n_slabs; k += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = *(const float4*)(slabs + (size_t)(k + u) * stride + 4 * i);
+        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+      }
+    }
+    for (; k < n_slabs; ++k) {
+      const float4 v = *(const float4*)(slabs + (size_t)k * stride + 4 * i);
+      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    }
+    float4 o;
+    o.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) * scale;
+    o.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) * scale;
+    o.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) * scale;
+    o.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) * scale;
+    *(float4*)(out + 4 * i) = o;
   }
 }
 
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
                               hipStream_t s) {
-  size_t blocks = (n + 255) / 256;
+  if ((n & 3) || (stride & 3)) return hipErrorInvalidValue;
+  size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, n_slabs, stride, n, scale, out);

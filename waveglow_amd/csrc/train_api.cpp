@@ -85,7 +85,7 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.GZ = (float*)take(w.rows8 * 4);
   const size_t K1 = 3 * (size_t)C + M8;
   w.slab = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
-  size_t part = (size_t)colsum_slabs(g) * max_sz(2 * (size_t)C, (size_t)M8);
+  size_t part = (size_t)max_sz((size_t)colsum_slabs(g), (size_t)kPhases * 4) * max_sz(2 * (size_t)C, (size_t)M8);
   part = max_sz(part, (size_t)flow_bwd_workgroups(g) * 64);
   part = max_sz(part, (size_t)start_wgrad_workgroups(g) * 5 * C);
   w.part = (float*)take(part * 4);
@@ -169,7 +169,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
     a.A = (const _Float16*)wt->wup;
     a.a_phase_stride = (long long)M8 * 512;
     a.ktot = 512;
-    a.lda = 512;
+    a.n_blk = M8 / 32;
     a.M = M8;
     a.bias = wt->bup;
     a.g = g;
@@ -229,7 +229,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.run[3] = run_of(w.SP, mc, 0);
         a.A = w1 + (size_t)fl * 2 * C * K1;
         a.ktot = K1;
-        a.lda = K1;
+        a.n_blk = 2 * C / 32;
         a.M = C;
         a.bias = wt->b1 + (size_t)fl * 2 * C;
         a.g = g;
@@ -245,7 +245,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.run[0] = run_of(Ai, cc, 0);
         a.A = w2 + (size_t)fl * C * C;
         a.ktot = C;
-        a.lda = C;
+        a.n_blk = C / 32;
         a.M = C;
         a.bias = wt->b2 + (size_t)fl * C;
         a.g = g;
@@ -260,7 +260,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.run[0] = run_of(Ai, cc, 0);
         a.A = wes + (size_t)fl * 32 * C;
         a.ktot = C;
-        a.lda = C;
+        a.n_blk = 1;
         a.M = 32;
         a.g = g;
         a.rows32 = w.OUT + (size_t)k * w.rows8;
@@ -286,9 +286,10 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
   const int C = x.C, nl = x.nl, M8 = x.M8, K1 = x.K1, FL = x.FL;
   const int cc = C / 64, mc = M8 / 64;
   const float inv = 1.0f / scale;
+  // the C x C and 64 x C weight gradients have few output tiles: cut every phase's rows into parts (more slabs)
+  const int small_split = (g.Rp % (4 * 32) == 0) ? 4 : 1;
   const _Float16* wat = (const _Float16*)wt->wat;
   const _Float16* wbt = (const _Float16*)wt->wbt;
-  const int n_cs = colsum_slabs(g);
 
   // channel offsets of the peeled outputs in z (model.py:201-203, :220)
   int z_final_ch0 = 0;
@@ -313,9 +314,6 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
     fb.GZ = w.GZ;
     fb.GO = w.GO;
     TR_TRY(launch_flow_bwd_pre(fb, s));
-    // d out_init = sum over columns of (d b | d log_s)
-    TR_TRY(launch_colsum(w.GO, 1, g, w.part, s));
-    TR_TRY(launch_slab_reduce(w.part, n_cs, 64, 8, inv, gr->dout_init[k], s));
 
     _Float16 *gx = nullptr, *gx_next = w.GX0;   // gx = d x_{i+1} (null: zero, the last layer has no res output)
     for (int i = nl - 1; i >= 0; --i) {
@@ -336,10 +334,10 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
         } else {
           a.n_runs = 1;
           a.run[0] = run_of(w.GO, 1, 0);
-          a.A = Am + C;
+          a.A = Am + (size_t)(C / 64) * (C / 32) * 2048;   // skip the K-steps of the (absent) d x_{i+1} run
           a.ktot = 64;
         }
-        a.lda = C + 64;
+        a.n_blk = C / 32;
         a.M = C;
         a.g = g;
         a.i0 = w.T + (size_t)fl * w.plane_c;
@@ -359,13 +357,14 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
         a.run[3] = run_of(w.SP, mc, 0);
         a.k_chunks = 3 * cc + mc;
         a.g = g;
+        a.row_split = 1;
         a.out = w.slab;
         a.out_scale = 1.0f;
+        a.bias_out = w.part;
         TR_TRY(launch_wgrad(a, s));
         const size_t n = (size_t)2 * C * K1;
         TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + (size_t)fl * n, s));
-        TR_TRY(launch_colsum(GPi, 2 * cc, g, w.part, s));
-        TR_TRY(launch_slab_reduce(w.part, n_cs, 2 * C, 2 * C, inv, gr->db1 + (size_t)fl * 2 * C, s));
+        TR_TRY(launch_slab_reduce(w.part, kPhases, 2 * C, 2 * C, inv, gr->db1 + (size_t)fl * 2 * C, s));
       }
       if (gx) {
         WgradArgs a;   // d W2 = d x_{i+1} x acts^T, d b2
@@ -376,13 +375,14 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
         a.run[0] = run_of(Ai, cc, 0);
         a.k_chunks = cc;
         a.g = g;
+        a.row_split = small_split;
         a.out = w.slab;
         a.out_scale = 1.0f;
+        a.bias_out = w.part;
         TR_TRY(launch_wgrad(a, s));
         const size_t n = (size_t)C * C;
-        TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw2 + (size_t)fl * n, s));
-        TR_TRY(launch_colsum(gx, cc, g, w.part, s));
-        TR_TRY(launch_slab_reduce(w.part, n_cs, C, C, inv, gr->db2 + (size_t)fl * C, s));
+        TR_TRY(launch_slab_reduce(w.slab, kPhases * small_split, n, n, inv, gr->dw2 + (size_t)fl * n, s));
+        TR_TRY(launch_slab_reduce(w.part, kPhases * small_split, C, C, inv, gr->db2 + (size_t)fl * C, s));
       }
       {
         WgradArgs a;   // d (W_end W_skip_i) = d out x acts^T
@@ -393,10 +393,14 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
         a.run[0] = run_of(Ai, cc, 0);
         a.k_chunks = cc;
         a.g = g;
+        a.row_split = small_split;
         a.out = w.slab;
         a.out_scale = 1.0f;
+        a.bias_out = (i == 0) ? w.part : nullptr;   // d out_init = sum over columns of (d b | d log_s), once per flow
         TR_TRY(launch_wgrad(a, s));
-        TR_TRY(launch_slab_reduce(w.slab, kPhases, (size_t)64 * C, (size_t)8 * C, inv, gr->dwes + (size_t)fl * 8 * C, s));
+        TR_TRY(launch_slab_reduce(w.slab, kPhases * small_split, (size_t)64 * C, (size_t)8 * C, inv,
+                                  gr->dwes + (size_t)fl * 8 * C, s));
+        if (i == 0) TR_TRY(launch_slab_reduce(w.part, kPhases * small_split, 64, 8, inv, gr->dout_init[k], s));
       }
       {
         PGemmArgs a;   // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)
@@ -407,7 +411,7 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
         a.run[2] = run_of(GPi, 2 * cc, -d);
         a.A = wbt + (size_t)fl * C * 6 * C;
         a.ktot = 6 * C;
-        a.lda = 6 * C;
+        a.n_blk = C / 32;
         a.M = C;
         a.g = g;
         a.i0 = gx;
@@ -453,7 +457,7 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
     a.run[0] = run_of(w.GP, FL * 2 * cc, 0);
     a.A = (const _Float16*)wt->wct;
     a.ktot = FL * 2 * C;
-    a.lda = FL * 2 * C;
+    a.n_blk = M8 / 32;
     a.M = M8;
     a.g = g;
     a.o0 = w.GSP;
@@ -468,11 +472,12 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
     for (int j = 0; j < 4; ++j) a.run[j] = run_of(w.MELP, 2, -32 * j);
     a.k_chunks = 8;
     a.g = g;
+    a.row_split = 1;
     a.out = gr->dwup;
     a.out_scale = inv;
+    a.bias_out = w.part;
     TR_TRY(launch_wgrad(a, s));
-    TR_TRY(launch_colsum(w.GSP, mc, g, w.part, s));
-    TR_TRY(launch_slab_reduce(w.part, n_cs, M8, M8, inv, gr->dbup, s));
+    TR_TRY(launch_slab_reduce(w.part, kPhases, M8, M8, inv, gr->dbup, s));
   }
   return WG_OK;
 }

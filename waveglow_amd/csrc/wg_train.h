@@ -3,8 +3,9 @@
 //
 // Everything here works on the same fp16 planes as the inference path (wg_common.h: RowGeom, phase-major rows,
 // position-major channels inside every 32-block).  Unlike inference, weights change every optimiser step, so no
-// weight is pre-packed on the host: every matrix arrives as a plain row-major fp16 device buffer [rows][K] in
-// "(pos,pos)" order (rows and K columns permuted by chan_to_pos inside 32-blocks, done by the caller), and the
+// weight is pre-packed on the host: the caller hands over every matrix as an fp16 device buffer in "(pos,pos)"
+// order (rows and K columns permuted by chan_to_pos inside 32-blocks) laid out in MFMA-fragment order (PGemmArgs::A;
+// one torch gather per matrix type and step), and the
 // cond_layer o upsample fold is NOT used (it would have to be rebuilt every step) -- the upsampled, squeezed
 // spectrogram exists as planes and cond_layer is a K-segment of GEMM 1.
 #pragma once
@@ -34,10 +35,13 @@ enum PEpi : int {
 struct PGemmArgs {
   PRun run[kMaxRuns];
   int n_runs;
-  const _Float16* A;        // [M_rows][ktot] fp16 row-major, (pos,pos) order
+  const _Float16* A;        // fp16 matrix in MFMA-fragment order [K/64 steps][n_blk][4 sub-steps][64 lanes][8]:
+                            //   lane (r = lane & 31, h = lane >> 5), element j of sub-step s of block b, step t
+                            //   = Mat[32 b + chan_to_pos(r)][64 t + 32 h + 8 s + j]   with Mat in (pos,pos) order
+                            // (a K offset of c chunks = A + c * n_blk * 2048)
   long long a_phase_stride; // elements added to A per phase (upsample: one matrix per phase), else 0
   int ktot;                 // sum of n_chunks * 64
-  int lda;                  // row stride of A in elements (>= ktot; A may point at a column offset)
+  int n_blk;                // 32-row blocks of the whole matrix (gate: 2C/32)
   int M;                    // EPI_GATE: C (rows per gate half, matrix has 2C rows); else number of matrix rows
   const float* bias;        // fp32, pos order, or null
   RowGeom g;
@@ -46,7 +50,8 @@ struct PGemmArgs {
   float* rows32;            // EPI_ES: OUT [B*L][8]
 };
 
-// dW[m][k'] = sum over the rows of one phase of G[row][m] * X[row(+shift)][k']  -> out[phase][m][k'] * out_scale
+// dW[m][k'] = sum over the rows of one slab of G[row][m] * X[row(+shift)][k']  -> out[slab][m][k'] * out_scale
+// slab = phase * row_split + part: a phase's Rp rows are cut into row_split parts (small GEMMs: more workgroups)
 struct WgradArgs {
   const _Float16* G;        // planes [m_chunks][R][64]
   int m_chunks;
@@ -54,8 +59,10 @@ struct WgradArgs {
   int n_runs;
   int k_chunks;             // sum n_chunks
   RowGeom g;
-  float* out;               // [32 phases][m_chunks*64][k_chunks*64] fp32
+  int row_split;            // 1, 2 or 4
+  float* out;               // [32*row_split slabs][m_chunks*64][k_chunks*64] fp32
   float out_scale;
+  float* bias_out;          // optional [slabs][m_chunks*64]: sum over the slab's rows of G (bias gradients), unscaled
 };
 
 // Row kernels of the flow backward (coupling, 1x1, start): model.py:200-218 differentiated.

@@ -95,6 +95,17 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
           torch.stack(w1x1).contiguous())
 
 
+def to_fragments(mat: torch.Tensor) -> torch.Tensor:
+  """[..., M, K] (pos,pos) fp16 -> MFMA-fragment order [..., K/64, M/32, 4, 64, 8] (wg_train.h: PGemmArgs::A):
+  lane (r, h), element j of sub-step s of block b, K-step t = mat[32b + chan_to_pos(r)][64t + 32h + 8s + j]."""
+  *lead, M, K = mat.shape
+  r = torch.arange(32)
+  c2p = (16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)).to(mat.device)
+  v = mat.reshape(*lead, M // 32, 32, K // 64, 2, 4, 8).index_select(len(lead) + 1, c2p)   # [.., b, r, t, h, s, j]
+  n = len(lead)
+  return v.permute(*range(n), n + 2, n, n + 4, n + 3, n + 1, n + 5).contiguous()            # [.., t, b, s, h, r, j]
+
+
 def _ptr(t: torch.Tensor) -> C.c_void_p:
   return C.c_void_p(t.data_ptr())
 
@@ -109,17 +120,18 @@ class _Weights:
     FL = w1.shape[0]
     dev = w1.device
     r32 = pos_perm(32).to(dev)
-    self.w1 = w1.half()
+    w1h, w2h = w1.half(), w2.half()
     self.b1, self.b2, self.bup = b1.float(), b2.float(), bup.float()
-    self.w2 = w2.half()
     hi = wes.half()
     lo = (wes - hi.float()).half()
     nat = torch.cat([hi, lo, torch.zeros_like(hi), torch.zeros_like(hi)], 1)     # natural MFMA rows 0..31
-    self.wes = nat[:, r32].contiguous()                    # matrix row chan_to_pos(r) holds MFMA row r
-    self.wat = torch.cat([self.w2.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2).contiguous()
-    self.wbt = torch.cat([self.w1[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2).contiguous()
-    self.wct = self.w1[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc).contiguous()
-    self.wup = wup.half()
+    self.w1 = to_fragments(w1h)
+    self.w2 = to_fragments(w2h)
+    self.wes = to_fragments(nat[:, r32])                   # matrix row chan_to_pos(r) holds MFMA row r
+    self.wat = to_fragments(torch.cat([w2h.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2))
+    self.wbt = to_fragments(torch.cat([w1h[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2))
+    self.wct = to_fragments(w1h[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc))
+    self.wup = to_fragments(wup.half())
     self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
     self.bstart = [start5[k, 4].contiguous().float() for k in range(nf)]
     self.out_init = [out_init[k].contiguous().float() for k in range(nf)]
