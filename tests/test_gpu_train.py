@@ -117,3 +117,17 @@ def test_train_step_c256_two_utterances():
   print(f"loss gpu {loss:.6f} oracle {float(loss_ref):.6f}")
   assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
   _check(grads, g_ref, "c256")
+
+
+@pytest.mark.parametrize("ct", ["2", "3", "4"])
+def test_train_step_every_tile_width(ct, monkeypatch):
+  """Rp = 384 rows per phase divides by 64, 96 and 128: the three tile widths of the plane GEMM give the same
+  gradients (the launcher normally picks the one with the fewest rounds)."""
+  from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_TRAIN_CT", ct)
+  over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 6, 50, 11, crop=72)
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check(grads, g_ref, "ct" + ct)

@@ -13,6 +13,7 @@
 // (the hand-scheduled inference kernel in kernels.hip is the template for tuning it).
 #include "wg_train.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace wg {
@@ -53,16 +54,17 @@ __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, in
 // as both operands agree.  (Reading fragments straight from a row-major matrix -- 64 lanes on 64 different cache
 // lines per load -- ran the whole kernel at the L1's line rate: 2.5x slower.)
 // =============================================================================================
-template <int EPI>
+template <int EPI, int CT>
 __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   constexpr int MT = (EPI == EPI_GATE) ? 2 : 1;
+  constexpr int BN = 32 * CT;    // tile width in rows; the B staging always moves 128 rows (rows >= BN are unused)
   __shared__ __attribute__((aligned(16))) _Float16 sB[2][128 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const RowGeom& g = a.g;
-  const int tpp = g.Rp >> 7;
+  const int tpp = g.Rp / BN;
   const int tile = blockIdx.x;
-  const int p = tile / tpp, r0 = (tile - p * tpp) << 7;
+  const int p = tile / tpp, r0 = (tile - p * tpp) * BN;
   const int blk = blockIdx.y * 8 + w;
   const bool active = blk * 32 < a.M;
   const size_t R64 = (size_t)g.R * 64;
@@ -74,11 +76,11 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   arow[0] = Ap + (size_t)ablk * 2048 + lane * 8;
   if (MT == 2) arow[MT - 1] = Ap + (size_t)(a.M / 32 + ablk) * 2048 + lane * 8;
 
-  f32x16 acc[MT][4];
+  f32x16 acc[MT][CT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[mt][ct][j] = 0.0f;
 
@@ -135,14 +137,14 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      half8 bf[4];
+      half8 bf[CT];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
         bf[ct] = *(const half8*)&sB[par][(ct * 32 + r) * 64 + (((4 * h + s) ^ (r & 7)) << 3)];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
           acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[par][mt][s], bf[ct], acc[mt][ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   // ---- epilogue: lane (column r of column tile ct, half h) holds matrix positions P0 .. P0+15 of its 32-block
   const int P0 = blk * 32 + 16 * h;
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     const int rr = r0 + ct * 32 + r;
     int b, t;
     const bool valid = column_valid(g, p, rr, b, t);
@@ -235,18 +237,58 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   }
 }
 
+namespace {
+template <int EPI>
+void launch_pg(const PGemmArgs& a, int ct, hipStream_t s) {
+  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), (a.M + 255) / 256);
+  if (ct == 4) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 4>), grid, dim3(512), 0, s, a);
+  else if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 3>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((plane_gemm_kernel<EPI, 2>), grid, dim3(512), 0, s, a);
+}
+int device_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+}  // namespace
+
+// Tile width: one workgroup per CU (8 waves x ~250 VGPRs), so a launch runs in ceil(tiles / CUs) rounds; among the
+// widths that divide Rp pick the one with the least rounds x width (config 4: Rp = 2304 -> 576 tiles of 128 would
+// be 3 rounds at 75 % occupancy; 768 tiles of 96 are exactly 3 full rounds of 3/4 the work).
+int plane_gemm_tile_cols(const RowGeom& g) {
+  if (const char* e = getenv("WG_TRAIN_CT")) {      // tests: pin the tile width (2, 3 or 4 column tiles of 32)
+    const int ct = atoi(e);
+    if (ct >= 2 && ct <= 4 && g.Rp % (32 * ct) == 0) return ct;
+  }
+  const int cus = device_cus();
+  int best = 0;
+  long long best_cost = 0;
+  for (int ct = 4; ct >= 2; --ct) {
+    if (g.Rp % (32 * ct)) continue;
+    const long long tiles = (long long)kPhases * (g.Rp / (32 * ct));
+    const long long cost = ((tiles + cus - 1) / cus) * ct;
+    if (!best || cost < best_cost) { best = ct; best_cost = cost; }
+  }
+  return best;
+}
+
 hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
   if (a.g.Rp % 128 || a.n_runs < 1 || a.n_runs > kMaxRuns || a.M < 1) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks * 64;
   if (k != a.ktot) return hipErrorInvalidValue;
-  dim3 grid(kPhases * (a.g.Rp / 128), (a.M + 255) / 256);
+  const int ct = plane_gemm_tile_cols(a.g);
   switch (epi) {
     case EPI_STORE16:
-    case EPI_RES: hipLaunchKernelGGL(plane_gemm_kernel<EPI_RES>, grid, dim3(512), 0, s, a); break;
-    case EPI_GATE: hipLaunchKernelGGL(plane_gemm_kernel<EPI_GATE>, grid, dim3(512), 0, s, a); break;
-    case EPI_ES: hipLaunchKernelGGL(plane_gemm_kernel<EPI_ES>, grid, dim3(512), 0, s, a); break;
-    case EPI_DGATE: hipLaunchKernelGGL(plane_gemm_kernel<EPI_DGATE>, grid, dim3(512), 0, s, a); break;
+    case EPI_RES: launch_pg<EPI_RES>(a, ct, s); break;
+    case EPI_GATE: launch_pg<EPI_GATE>(a, ct, s); break;
+    case EPI_ES: launch_pg<EPI_ES>(a, ct, s); break;
+    case EPI_DGATE: launch_pg<EPI_DGATE>(a, ct, s); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
