@@ -146,3 +146,73 @@ def test_stft_oracle_is_self_consistent():
   np.testing.assert_allclose(f32, fwd, atol=1e-6)
   np.testing.assert_allclose(i32, inv, atol=1e-6)
   np.testing.assert_allclose(w32, wsq, atol=1e-6)
+
+
+def test_training_weight_packing_reproduces_the_reference_forward():
+  """Host logic of the training direction (waveglow_amd/train.py: pack_weights) without the GPU: a plain-torch
+  evaluation of exactly the matrices the library receives -- (pos,pos) permutation, tap-major K, cond slice as a
+  K-segment, W_end folded into the skip rows, per-phase upsample matrices -- must reproduce the oracle's forward."""
+  import torch
+  from oracle import torch_oracle as O
+  from _cases import oracle_cfg_from_hp
+  from waveglow_amd import synthetic
+  from waveglow_amd.hparams import HParams
+  from waveglow_amd.model import WaveGlow
+  from waveglow_amd.train import pack_weights, pos_perm, to_fragments
+  hp = HParams(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=2))
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  B, T = 2, 5
+  mel = synthetic.make_mel(B, T, seed=9)
+  S = 256 * T - 64
+  wav = torch.rand(B, S, generator=torch.Generator().manual_seed(1)) * 0.6 - 0.3
+  with torch.no_grad():
+    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = pack_weights(model)
+    C_, nl, M8 = hp.n_channels, hp.n_layers, hp.n_mel_channels * 8
+    L = S // 8
+    pc, pm = pos_perm(C_), pos_perm(M8)
+    # upsample + squeeze through the per-phase matrices: spect[pos][b][t], t = 32 q + p
+    melp = torch.nn.functional.pad(mel, (3, 0))                               # frames q-3 .. q
+    spect = torch.zeros(M8, B, L)
+    for t in range(L):
+      p, q = t % 32, t // 32
+      taps = torch.stack([torch.nn.functional.pad(melp[:, :, q + 3 - j], (0, 128 - hp.n_mel_channels)) for j in range(4)], 1)
+      spect[:, :, t] = wup[p] @ taps.reshape(B, 512).t() + bup[:, None]
+    audio = wav.view(B, L, 8).permute(0, 2, 1)                                # [B, 8, L]
+    outs, log_s_all = [], []
+    for k in range(model.n_flows):
+      if k % hp.n_early_every == 0 and k > 0:
+        outs.append(audio[:, :hp.n_early_size])
+        audio = audio[:, hp.n_early_size:]
+      c = audio.shape[1]
+      h = c // 2
+      audio = torch.einsum("rc,bcl->brl", w1x1[k, :c, :c], audio)
+      a0, a1 = audio[:, :h], audio[:, h:]
+      x = torch.einsum("pj,bjl->pbl", start5[k, :h].t(), a0) + start5[k, 4][:, None, None]     # [C pos, B, L]
+      out = out_init[k][:, None, None].expand(8, B, L).clone()
+      for i in range(nl):
+        fl, d = k * nl + i, 2 ** i
+        xp = torch.nn.functional.pad(x, (d, d))
+        kin = torch.cat([xp[:, :, 0:L], xp[:, :, d:d + L], xp[:, :, 2 * d:2 * d + L], spect], 0)  # K = tap0|tap1|tap2|spect
+        pre = torch.einsum("mk,kbl->mbl", w1[fl], kin) + b1[fl][:, None, None]
+        acts = torch.tanh(pre[:C_]) * torch.sigmoid(pre[C_:])
+        if i < nl - 1:
+          x = x + torch.einsum("mk,kbl->mbl", w2[fl], acts) + b2[fl][:, None, None]
+        out = out + torch.einsum("mk,kbl->mbl", wes[fl], acts)
+      b_, ls = out[:h].permute(1, 0, 2), out[h:2 * h].permute(1, 0, 2)
+      audio = torch.cat([a0, torch.exp(ls) * a1 + b_], 1)
+      log_s_all.append(ls)
+    outs.append(audio)
+    z = torch.cat(outs, 1)
+    dense = {k_: v.detach() for k_, v in model.dense_state().items()}
+    z_ref, ls_ref, _ = O.forward_ref(dense, mel, wav, oracle_cfg_from_hp(hp))
+  assert float((z - z_ref).abs().max()) < 2e-4
+  for a, b in zip(log_s_all, ls_ref):
+    assert float((a - b).abs().max()) < 2e-4
+  # fragment order: element (t, b, s, h, r, j) = mat[32 b + chan_to_pos(r)][64 t + 32 h + 8 s + j]
+  m = torch.arange(64 * 128, dtype=torch.float32).reshape(64, 128)
+  f = to_fragments(m)
+  c2p = lambda r: 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)
+  for (t, b, s_, h_, r, j) in [(0, 0, 0, 0, 0, 0), (1, 1, 2, 1, 5, 3), (1, 0, 3, 0, 31, 7)]:
+    assert float(f[t, b, s_, h_, r, j]) == float(m[32 * b + c2p(r), 64 * t + 32 * h_ + 8 * s_ + j])
