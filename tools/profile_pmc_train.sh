@@ -1,0 +1,20 @@
+#!/bin/bash
+# PMC passes for the training step (tools/bench_train.py), one counter group per run, never combined with tracing.
+# usage: tools/profile_pmc_train.sh <tag>
+set -u
+TAG=${1:-train}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { # name counters...
+  local name=$1; shift
+  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/tools/bench_train.py --steps 1 --warmup 0 > $OUT/$name.log 2>&1 || echo "pass $name failed"
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16
+run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU
+run sq3 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL
+run grbm GRBM_GUI_ACTIVE
+run tcc TCC_HIT_sum TCC_MISS_sum
+run fetch FETCH_SIZE
+python3 $ROOT/tools/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1
