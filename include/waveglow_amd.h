@@ -141,6 +141,13 @@ int wg_stft_denoise(wg_stft* h, const float* audio, const float* bias_mag, float
                     float* mag0_out, int32_t B, int32_t n_samples, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Mel front-end, TacotronSTFT.mel_spectrogram (src/waveglow/taco_stft.py:84-104): STFT magnitudes (reflect padding,
+ * stft.py:141-152) x mel filterbank -> log(clamp(., 1e-5)).  audio [B][n_samples] fp32 device (any n_samples > 512),
+ * mel_basis [n_mel][513] fp32 DEVICE, mel_out [B][n_mel][n_samples/256 + 1] fp32 device.  Enqueue-only. */
+size_t wg_stft_mel_workspace_bytes(const wg_stft* h, int32_t B, int32_t n_samples);
+int wg_stft_mel(wg_stft* h, const float* mel_basis, int32_t n_mel, const float* audio, float* mel_out, int32_t B,
+                int32_t n_samples, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Training direction: WaveGlow.forward under autograd and loss.backward() ---------------------------------------
  * (src/waveglow/model.py:178-221, train.py:190-199).  Weights change every optimiser step, so they are NOT taken from
  * the handle: the caller passes device buffers.  Every fp16 matrix below is given as [rows][K] in "(pos,pos)" order

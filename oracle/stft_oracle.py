@@ -58,3 +58,12 @@ def denoise(audio, bias_mag, strength, fwd, inv, win_sq):
   ph = np.arctan2(im, re)
   mag_d = np.clip(mag - bias_mag[None, :, None] * strength, 0.0, None)
   return inverse(mag_d * np.cos(ph), mag_d * np.sin(ph), inv, win_sq)
+
+
+def mel_spectrogram(audio: np.ndarray, mel_basis: np.ndarray, filter_length=1024, hop_length=256, win_length=1024):
+  """TacotronSTFT.mel_spectrogram (src/waveglow/taco_stft.py:84-104) in fp64: log(clamp(mel_basis @ |STFT(audio)|, 1e-5)).
+  audio [B, N] -> [B, n_mel, N // hop + 1].  Parity unpinned against the reference (librosa absent), see header."""
+  fwd, _, _ = bases(filter_length, hop_length, win_length)
+  re, im = transform(np.asarray(audio, dtype=np.float64), fwd, filter_length, hop_length)
+  mel = np.einsum("mk,bkf->bmf", mel_basis.astype(np.float64), np.sqrt(re ** 2 + im ** 2))
+  return np.log(np.maximum(mel, 1e-5))

@@ -216,3 +216,49 @@ def test_training_weight_packing_reproduces_the_reference_forward():
   c2p = lambda r: 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)
   for (t, b, s_, h_, r, j) in [(0, 0, 0, 0, 0, 0), (1, 1, 2, 1, 5, 3), (1, 0, 3, 0, 31, 7)]:
     assert float(f[t, b, s_, h_, r, j]) == float(m[32 * b + c2p(r), 64 * t + 32 * h_ + 8 * s_ + j])
+
+
+def test_checkpoint_cadence_and_resume_bookkeeping():
+  """utils.py:361-470 restated in waveglow_amd/training.py: which iterations save, and where a resumed run continues."""
+  from waveglow_amd.training import (SaveIterationSettings, check_save_it, get_continue_batch_iteration,
+                                     get_continue_epoch, iteration_to_batch_iteration, iteration_to_epoch, skip_batch)
+  st = SaveIterationSettings(epochs=2, batch_iterations=5, save_first_iteration=True, save_last_iteration=True,
+                             iters_per_checkpoint=3, epochs_per_checkpoint=1)
+  saves = [it for it in range(1, 11) if check_save_it(iteration_to_epoch(it, 5), it, st)]
+  assert saves == [1, 3, 5, 6, 9, 10]            # first, every 3rd, the last batch of every epoch, the last
+  st2 = SaveIterationSettings(epochs=3, batch_iterations=4, save_first_iteration=False, save_last_iteration=False,
+                              iters_per_checkpoint=0, epochs_per_checkpoint=2)
+  assert [it for it in range(1, 13) if check_save_it(iteration_to_epoch(it, 4), it, st2)] == [8]
+  assert iteration_to_epoch(1, 5) == 0 and iteration_to_epoch(5, 5) == 0 and iteration_to_epoch(6, 5) == 1
+  assert iteration_to_batch_iteration(6, 5) == 0 and iteration_to_batch_iteration(10, 5) == 4
+  # a checkpoint of iteration 7 with 5 batches per epoch continues in epoch 1 at batch 2
+  assert get_continue_epoch(7, 5) == 1 and get_continue_batch_iteration(7, 5) == 2
+  assert skip_batch(continue_batch_iteration=2, batch_iteration=1) and not skip_batch(continue_batch_iteration=2, batch_iteration=2)
+  assert get_continue_epoch(0, 5) == 0 and get_continue_batch_iteration(0, 5) == 0
+
+
+def test_slaney_mel_filterbank_and_mel_oracle():
+  """librosa.filters.mel restated (taco_stft.py:66-73 calls it with sr 22050, n_fft 1024, 80 mels, 0-8000 Hz):
+  closed-form anchors of the Slaney scale, triangle/area properties, and the numpy mel oracle on a pure tone."""
+  import numpy as np
+  from waveglow_amd.taco_stft import _hz_to_mel, _mel_to_hz, slaney_mel_filterbank
+  from oracle import stft_oracle as S
+  assert abs(float(_hz_to_mel(1000.0)) - 15.0) < 1e-12                      # linear part: 200/3 Hz per mel
+  assert abs(float(_hz_to_mel(8000.0)) - (15.0 + np.log(8.0) / (np.log(6.4) / 27.0))) < 1e-9
+  assert abs(float(_mel_to_hz(_hz_to_mel(4321.0))) - 4321.0) < 1e-9
+  fb = slaney_mel_filterbank(22050, 1024, 80, 0.0, 8000.0)
+  assert fb.shape == (80, 513) and fb.dtype == np.float32 and (fb >= 0).all()
+  freqs = np.linspace(0, 11025, 513)
+  assert (fb[:, freqs > 8000.0] == 0).all() and fb[:, 0].sum() == 0         # nothing above fmax; first triangle starts at 0 Hz
+  centres = freqs[fb.argmax(axis=1)]
+  assert (np.diff(centres) > 0).all()
+  # Slaney normalisation: every triangle has (continuous) unit area -> discrete area within the bin quantisation
+  area = fb.sum(axis=1) * (freqs[1] - freqs[0])
+  assert np.all(np.abs(area - 1.0) < 0.35) and abs(area[40:].mean() - 1.0) < 0.02
+  t = np.arange(8192) / 22050.0
+  tone = 0.5 * np.sin(2 * np.pi * 2000.0 * t)[None, :]
+  mel = S.mel_spectrogram(tone, fb)
+  assert mel.shape == (1, 80, 8192 // 256 + 1)
+  peak = int(mel[0, :, 10].argmax())
+  assert abs(centres[peak] - 2000.0) < 80.0
+  assert mel.min() >= np.log(1e-5) - 1e-12

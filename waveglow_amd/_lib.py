@@ -71,6 +71,9 @@ SIGNATURES = {
   "wg_stft_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
   "wg_stft_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+  "wg_stft_mel_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+  "wg_stft_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                            C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_debug_set_stamp_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
   "wg_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
   "wg_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),

@@ -39,8 +39,8 @@ def convert_wav(wav: np.ndarray, to_dtype) -> np.ndarray:
   """float [-1,1] -> integer PCM with rounding (audio_utils.py:36-64)."""
   if wav.dtype != to_dtype:
     _, hi = _min_max(to_dtype)
-    _, cur_hi = _min_max(wav.dtype)
-    wav = wav / cur_hi * hi
+    cur_lo, _ = _min_max(wav.dtype)
+    wav = wav / (-1 * cur_lo) * hi              # the reference divides by -min of the source type
     if to_dtype in (np.int16, np.int32):
       wav = np.round(wav, 0)
     wav = wav.astype(to_dtype)
@@ -49,3 +49,20 @@ def convert_wav(wav: np.ndarray, to_dtype) -> np.ndarray:
 
 def float_to_wav(wav: np.ndarray, path, dtype=np.int16, sample_rate: int = 22050) -> None:
   write(filename=path, rate=sample_rate, data=convert_wav(wav, dtype))
+
+
+def wav_to_float32(path):
+  """(float32 samples in [-1, 1], sampling rate) of a PCM wav file (audio_utils.py:206-216)."""
+  from scipy.io.wavfile import read
+  sampling_rate, wav = read(path)
+  return convert_wav(wav, np.float32), sampling_rate
+
+
+def get_wav_tensor_segment(wav_tensor, segment_length: int):
+  """Random segment of the training length, or zero padding up to it (audio_utils.py:141-150)."""
+  import random
+  import torch
+  if wav_tensor.size(0) >= segment_length:
+    audio_start = random.randint(0, wav_tensor.size(0) - segment_length)
+    return wav_tensor[audio_start:audio_start + segment_length]
+  return torch.nn.functional.pad(wav_tensor, (0, segment_length - wav_tensor.size(0)), "constant").data

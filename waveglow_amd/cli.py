@@ -4,6 +4,10 @@ commented-out ``--batch-size``, inference_v2.py:64) and per-rank sharding of the
 
   python -m waveglow_amd.cli synthesize CHECKPOINT FOLDER [--sigma S] [--denoiser-strength D] [--device cuda:0]
          [--custom-hparams a=1,b=2] [--custom-seed N] [-out DIR] [-o]
+  python -m waveglow_amd.cli train TRAIN-FOLDER VAL-FOLDER CHECKPOINTS-FOLDER [--device cuda:0] [--custom-hparams ...]
+         [--pre-trained-model CKPT --warm-start]                     (src/waveglow_cli/training.py:24-79)
+  python -m waveglow_amd.cli continue-train TRAIN-FOLDER VAL-FOLDER CHECKPOINTS-FOLDER [...]   (training.py:82-124)
+Under ``python -m torch.distributed.run`` the training commands run data-parallel (one process per GPU, RCCL).
 """
 from __future__ import annotations
 
@@ -44,7 +48,41 @@ def build_parser() -> argparse.ArgumentParser:
   s.add_argument("--custom-seed", type=int, default=None)
   s.add_argument("-out", "--output-directory", type=Path, default=None)
   s.add_argument("-o", "--overwrite", action="store_true")
+  for name, desc in (("train", "Start training of a new model."), ("continue-train", "Continue training from the last checkpoint.")):
+    t = sub.add_parser(name, description=desc)
+    t.add_argument("train_folder", type=Path, metavar="TRAIN-FOLDER")
+    t.add_argument("val_folder", type=Path, metavar="VAL-FOLDER")
+    t.add_argument("checkpoints_dir", type=Path, metavar="CHECKPOINTS-FOLDER")
+    t.add_argument("--device", type=str, default="cuda:0")
+    t.add_argument("--custom-hparams", type=str, default=None)
+    if name == "train":
+      t.add_argument("--pre-trained-model", type=Path, default=None)
+      t.add_argument("--warm-start", action="store_true")
   return p
+
+
+def train_cmd(ns, resume: bool) -> bool:
+  from .training import get_last_checkpoint, load_dataset, train
+  rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+  device = torch.device(ns.device if world == 1 else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+  torch.cuda.set_device(device)
+  if world > 1 and not torch.distributed.is_initialized():
+    torch.distributed.init_process_group("nccl", device_id=device)
+  for d in (ns.train_folder, ns.val_folder):
+    if not d.is_dir():
+      getLogger(__name__).error(f"{d} is not a directory!")
+      return False
+  checkpoint = warm = None
+  if resume:
+    checkpoint = CheckpointWaveglow.load(get_last_checkpoint(ns.checkpoints_dir)[0], device)
+  elif ns.pre_trained_model is not None and ns.warm_start:
+    warm = CheckpointWaveglow.load(ns.pre_trained_model, device)
+  train(custom_hparams=split_hparams_string(ns.custom_hparams), logdir=None, trainset=load_dataset(ns.train_folder),
+        valset=load_dataset(ns.val_folder), save_checkpoint_dir=ns.checkpoints_dir, checkpoint=checkpoint,
+        warm_model=warm, device=device)
+  if world > 1:
+    torch.distributed.destroy_process_group()
+  return True
 
 
 def synthesize(ns) -> bool:
@@ -77,7 +115,10 @@ def synthesize(ns) -> bool:
 
 def main(argv=None) -> int:
   ns = build_parser().parse_args(argv)
-  ok = synthesize(ns) if ns.command == "synthesize" else False
+  if ns.command == "synthesize":
+    ok = synthesize(ns)
+  else:
+    ok = train_cmd(ns, resume=ns.command == "continue-train")
   return 0 if ok else 1
 
 

@@ -22,6 +22,13 @@ struct StftArgs {
   float* rec;              // [B][1056][Fs]   Fs = 3 + Fpad (3 zero lead columns), recombined spectrum
   float* mag0;             // optional [B][513]: magnitude of frame 0
   int N, F, Fs;
+  float* mag;              // optional [B][513][F]: all magnitudes (mel front-end); rec may then be null
+};
+struct MelArgs {
+  const float* mag;        // [B][513][F]
+  const float* basis;      // [n_mel][513]  Slaney mel filterbank (taco_stft.py:66-73)
+  float* mel;              // [B][n_mel][F]  log(clamp(basis . mag, 1e-5))   (taco_stft.py:10-16, :99-104)
+  int n_mel, F;
 };
 struct IstftArgs {
   const float* rec;        // [B][1056][Fs]
@@ -82,6 +89,8 @@ __global__ void __launch_bounds__(512) stft_kernel(const StftArgs a) {
         if (bin < kCut && f < a.F) {
           const float mag = sqrtf(re * re + im * im);
           if (a.mag0 && f == 0) a.mag0[(size_t)b * kCut + bin] = mag;
+          if (a.mag) a.mag[((size_t)b * kCut + bin) * a.F + f] = mag;
+          if (!a.rec) continue;
           if (a.bias) {                                 // denoiser.py:54-55, recombined with the original phase
             const float md = fmaxf(mag - a.bias[bin] * a.strength, 0.0f);
             const float sc = mag > 0.0f ? md / mag : 0.0f;
@@ -134,6 +143,37 @@ __global__ void __launch_bounds__(512) istft_kernel(const IstftArgs a) {
       a.out[(size_t)b * a.N + o] = v * (float)(kFL / kHop);
     }
   }
+}
+
+// mel[b][m][f] = log(max(sum_k basis[m][k] |X|[b][k][f], 1e-5)): 80 x 513 MACs per frame, HBM/VALU-trivial.
+// grid (ceil(F/64), B), 256 threads = 64 frames x 4 groups of mel rows.
+__global__ void __launch_bounds__(256) mel_kernel(const MelArgs a) {
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6, b = blockIdx.y;
+  const int per = (a.n_mel + 3) / 4;
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+  const float* mp = a.mag + (size_t)b * kCut * a.F + (f < a.F ? f : a.F - 1);
+  for (int k = 0; k < kCut; ++k) {
+    const float v = mp[(size_t)k * a.F];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int m = grp * per + i;
+      if (i < per && m < a.n_mel) acc[i] = fmaf(a.basis[(size_t)m * kCut + k], v, acc[i]);
+    }
+  }
+  if (f >= a.F) return;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int m = grp * per + i;
+    if (i < per && m < a.n_mel) a.mel[((size_t)b * a.n_mel + m) * a.F + f] = logf(fmaxf(acc[i], 1e-5f));
+  }
+}
+
+hipError_t launch_mel(const MelArgs& a, int B, hipStream_t s) {
+  if (a.n_mel < 1 || a.n_mel > 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mel_kernel, dim3((a.F + 63) / 64, B), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_stft(const StftArgs& a, int B, hipStream_t s) {

@@ -10,7 +10,12 @@ namespace wg {
 constexpr int kFL = 1024, kHop = 256, kCut = 513, kRows = 1056;
 struct StftArgs {
   const float* audio; const float* fwdA; const float* bias; float strength; float* rec; float* mag0; int N, F, Fs;
+  float* mag;
 };
+struct MelArgs {
+  const float* mag; const float* basis; float* mel; int n_mel, F;
+};
+hipError_t launch_mel(const MelArgs& a, int B, hipStream_t s);
 struct IstftArgs {
   const float* rec; const float* invA; const float* win_sq; float* out; int N, F, Fs;
 };
@@ -97,12 +102,32 @@ int wg_stft_denoise(wg_stft* h, const float* audio, const float* bias_mag, float
   hipStream_t s = (hipStream_t)stream;
   const int F = n_samples / kHop + 1, Fs = frames_padded(F);
   HIP_TRY2(hipMemsetAsync(workspace, 0, need, s));           // zero lead/tail columns and pad rows
-  StftArgs a{audio, h->d_fwdA, bias_mag, strength, (float*)workspace, mag0_out, n_samples, F, Fs};
+  StftArgs a{audio, h->d_fwdA, bias_mag, strength, (float*)workspace, mag0_out, n_samples, F, Fs, nullptr};
   HIP_TRY2(launch_stft(a, B, s));
   if (audio_out) {
     IstftArgs b{(const float*)workspace, h->d_invA, h->d_win, audio_out, n_samples, F, Fs};
     HIP_TRY2(launch_istft(b, B, s));
   }
+  return WG_OK;
+}
+
+size_t wg_stft_mel_workspace_bytes(const wg_stft* h, int32_t B, int32_t n_samples) {
+  if (!h || B < 1 || n_samples < kFL / 2 + 1) return 0;          // reflect padding needs n_samples > filter/2
+  return (size_t)B * kCut * (n_samples / kHop + 1) * 4;
+}
+
+int wg_stft_mel(wg_stft* h, const float* mel_basis, int32_t n_mel, const float* audio, float* mel_out, int32_t B,
+                int32_t n_samples, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !mel_basis || !audio || !mel_out || !workspace) return wg_set_error(WG_ERR_INVALID, "null argument");
+  const size_t need = wg_stft_mel_workspace_bytes(h, B, n_samples);
+  if (!need || n_mel < 1 || n_mel > 128) return wg_set_error(WG_ERR_INVALID, "bad B / n_samples / n_mel");
+  if (workspace_bytes < need) return wg_set_error(WG_ERR_WORKSPACE, "mel workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int F = n_samples / kHop + 1;                             // stft.py:141-152: reflect pad filter/2 both sides
+  StftArgs a{audio, h->d_fwdA, nullptr, 0.0f, nullptr, nullptr, n_samples, F, 0, (float*)workspace};
+  HIP_TRY2(launch_stft(a, B, s));
+  MelArgs m{(const float*)workspace, mel_basis, mel_out, n_mel, F};
+  HIP_TRY2(launch_mel(m, B, s));
   return WG_OK;
 }
 
