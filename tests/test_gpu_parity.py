@@ -238,6 +238,14 @@ def test_synthesizer_and_cli_end_to_end(tmp_path):
   assert rc == 0
   rate, data = wavfile.read(out / "sub" / "a.wav")
   assert rate == 22050 and data.dtype == np.int16 and data.shape == (12 * 256,) and np.abs(data).max() == 32767
+  # copy synthesis: wav -> mel (HIP front-end) -> wav  (waveglow-cli synthesize-wav, inference_wav.py:74-130)
+  out2 = tmp_path / "out2"
+  rc = cli.main(["synthesize-wav", str(ck_path), str(out), "--sigma", "0.7", "--custom-seed", "3",
+                 "--device", "cuda:0", "-out", str(out2)])
+  assert rc == 0
+  rate2, data2 = wavfile.read(out2 / "sub" / "a.wav")
+  # 3072 input samples -> 13 mel frames -> 13 * 256 output samples
+  assert rate2 == 22050 and data2.dtype == np.int16 and data2.shape == (13 * 256,) and np.abs(data2).max() == 32767
 
 
 def test_denoiser_stft_vs_numpy_oracle():

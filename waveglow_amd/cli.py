@@ -4,6 +4,8 @@ commented-out ``--batch-size``, inference_v2.py:64) and per-rank sharding of the
 
   python -m waveglow_amd.cli synthesize CHECKPOINT FOLDER [--sigma S] [--denoiser-strength D] [--device cuda:0]
          [--custom-hparams a=1,b=2] [--custom-seed N] [-out DIR] [-o]
+  python -m waveglow_amd.cli synthesize-wav CHECKPOINT FOLDER [same flags]   wav -> mel (HIP front-end) -> wav
+         (src/waveglow_cli/inference_wav.py:74-130; copy synthesis)
   python -m waveglow_amd.cli train TRAIN-FOLDER VAL-FOLDER CHECKPOINTS-FOLDER [--device cuda:0] [--custom-hparams ...]
          [--pre-trained-model CKPT --warm-start]                     (src/waveglow_cli/training.py:24-79)
   python -m waveglow_amd.cli continue-train TRAIN-FOLDER VAL-FOLDER CHECKPOINTS-FOLDER [...]   (training.py:82-124)
@@ -38,16 +40,18 @@ def _unit_float(v: str) -> float:
 def build_parser() -> argparse.ArgumentParser:
   p = argparse.ArgumentParser(prog="waveglow-cli")
   sub = p.add_subparsers(dest="command", required=True)
-  s = sub.add_parser("synthesize", description="Synthesize mel-spectrograms to audio files (.wav).")
-  s.add_argument("checkpoint", type=Path, metavar="CHECKPOINT")
-  s.add_argument("folder", type=Path, metavar="FOLDER")
-  s.add_argument("--sigma", type=_unit_float, default=1.0)
-  s.add_argument("--denoiser-strength", type=_unit_float, default=0.0005)
-  s.add_argument("--device", type=str, default="cuda:0")
-  s.add_argument("--custom-hparams", type=str, default=None)
-  s.add_argument("--custom-seed", type=int, default=None)
-  s.add_argument("-out", "--output-directory", type=Path, default=None)
-  s.add_argument("-o", "--overwrite", action="store_true")
+  for name, desc in (("synthesize", "Synthesize mel-spectrograms to audio files (.wav)."),
+                     ("synthesize-wav", "Re-synthesize audio files: wav -> mel-spectrogram -> wav.")):
+    s = sub.add_parser(name, description=desc)
+    s.add_argument("checkpoint", type=Path, metavar="CHECKPOINT")
+    s.add_argument("folder", type=Path, metavar="FOLDER")
+    s.add_argument("--sigma", type=_unit_float, default=1.0)
+    s.add_argument("--denoiser-strength", type=_unit_float, default=0.0005)
+    s.add_argument("--device", type=str, default="cuda:0")
+    s.add_argument("--custom-hparams", type=str, default=None)
+    s.add_argument("--custom-seed", type=int, default=None)
+    s.add_argument("-out", "--output-directory", type=Path, default=None)
+    s.add_argument("-o", "--overwrite", action="store_true")
   for name, desc in (("train", "Start training of a new model."), ("continue-train", "Continue training from the last checkpoint.")):
     t = sub.add_parser(name, description=desc)
     t.add_argument("train_folder", type=Path, metavar="TRAIN-FOLDER")
@@ -85,7 +89,7 @@ def train_cmd(ns, resume: bool) -> bool:
   return True
 
 
-def synthesize(ns) -> bool:
+def synthesize(ns, from_wav: bool = False) -> bool:
   logger = getLogger(__name__)
   rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
   device = torch.device(ns.device if world == 1 else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
@@ -99,14 +103,22 @@ def synthesize(ns) -> bool:
   except Exception:
     logger.error("Checkpoint couldn't be loaded!")
     return False
-  mel_files = sorted(p for p in ns.folder.rglob("*") if p.is_file() and p.suffix.lower() == ".npy")
+  suffix = ".wav" if from_wav else ".npy"
+  mel_files = sorted(p for p in ns.folder.rglob("*") if p.is_file() and p.suffix.lower() == suffix)
   mel_files = shard_list(mel_files, rank, world)
   synth = Synthesizer(ckpt, custom_hparams=split_hparams_string(ns.custom_hparams), device=device)
+  taco_stft = None
+  if from_wav:
+    from .taco_stft import TacotronSTFT
+    taco_stft = TacotronSTFT(synth.hparams, device)                   # inference_wav.py:110
   for mel_path in mel_files:
     wav_path = out_dir / mel_path.relative_to(ns.folder).parent / f"{mel_path.stem}.wav"
     if wav_path.exists() and not ns.overwrite:
       continue
-    mel = torch.FloatTensor(np.load(mel_path)).unsqueeze(0)
+    if from_wav:
+      mel = taco_stft.get_mel_tensor_from_file(mel_path).unsqueeze(0)
+    else:
+      mel = torch.FloatTensor(np.load(mel_path)).unsqueeze(0)
     res = synth.infer(mel, sigma=ns.sigma, denoiser_strength=ns.denoiser_strength, seed=seed)
     wav_path.parent.mkdir(parents=True, exist_ok=True)
     float_to_wav(normalize_wav(res.wav_denoised), wav_path, sample_rate=res.sampling_rate)
@@ -115,8 +127,8 @@ def synthesize(ns) -> bool:
 
 def main(argv=None) -> int:
   ns = build_parser().parse_args(argv)
-  if ns.command == "synthesize":
-    ok = synthesize(ns)
+  if ns.command in ("synthesize", "synthesize-wav"):
+    ok = synthesize(ns, from_wav=ns.command == "synthesize-wav")
   else:
     ok = train_cmd(ns, resume=ns.command == "continue-train")
   return 0 if ok else 1
