@@ -131,3 +131,22 @@ def test_train_step_every_tile_width(ct, monkeypatch):
   loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
   assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
   _check(grads, g_ref, "ct" + ct)
+
+
+def test_backward_after_a_second_forward_raises():
+  """One training workspace per model: a second forward() overwrites the saved activations, so the first graph's
+  backward must fail loudly instead of producing gradients from the wrong activations."""
+  from waveglow_amd._lib import WgError
+  over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 6, 2)
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  crit = WaveGlowLoss(1.0)
+  l1 = crit(model((mel.cuda(), wav.cuda())), None)
+  l2 = crit(model((mel.cuda(), wav.cuda())), None)
+  with pytest.raises(WgError):
+    l1.backward()
+  l2.backward()
+  with pytest.raises((WgError, RuntimeError)):
+    l2.backward()

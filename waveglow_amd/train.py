@@ -160,11 +160,13 @@ class _TrainFn(torch.autograd.Function):
     if nbytes == 0:
       raise _lib.WgError(lib.wg_last_error().decode())
     ws, fresh = eng.train_workspace(nbytes, (B, F_, S))
+    eng.train_generation = getattr(eng, "train_generation", 0) + 1    # the workspace now holds THIS forward's activations
     ls = (C.c_void_p * len(log_s))(*[t.data_ptr() for t in log_s])
     stream = torch.cuda.current_stream(mel.device).cuda_stream
     _lib.check(lib.wg_train_forward(eng.handle, C.byref(wts.struct), _ptr(mel), _ptr(audio), _ptr(z), ls, B, F_, S,
                                     1 if fresh else 0, _ptr(ws), ws.numel(), C.c_void_p(stream)))
     ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio = model, wts, ws, (B, F_, S), audio
+    ctx.generation = eng.train_generation
     ctx.scale = float(scale) if scale else float(2.0 ** round(math.log2(z.numel())))
     ctx.shapes = [t.shape for t in packed]
     return (z, *log_s)
@@ -174,6 +176,9 @@ class _TrainFn(torch.autograd.Function):
     model, wts = ctx.model, ctx.wts
     eng = model._engine
     lib = eng.lib
+    if ctx.wts is None or ctx.generation != eng.train_generation:
+      raise _lib.WgError("the saved activations of this forward pass are gone (backward already ran, or a later "
+                         "forward() reused the training workspace): call backward() once, before the next forward()")
     B, F_, S = ctx.dims
     dev = ctx.audio.device
     nf = model.n_flows
