@@ -119,9 +119,9 @@ def test_train_step_c256_two_utterances():
   _check(grads, g_ref, "c256")
 
 
-@pytest.mark.parametrize("ct", ["2", "3", "4"])
+@pytest.mark.parametrize("ct", ["2", "3", "4", "6"])
 def test_train_step_every_tile_width(ct, monkeypatch):
-  """Rp = 384 rows per phase divides by 64, 96 and 128: the three tile widths of the plane GEMM give the same
+  """Rp = 384 rows per phase divides by 64, 96, 128 and 192: every tile width of the plane GEMM gives the same
   gradients (the launcher normally picks the one with the fewest rounds)."""
   from oracle import torch_oracle as O
   monkeypatch.setenv("WG_TRAIN_CT", ct)

@@ -45,8 +45,11 @@ __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, in
 }  // namespace
 
 // =============================================================================================
-// plane GEMM.  Workgroup = 8 waves = one tile of 128 consecutive rows of one phase x 256 matrix rows (x 2 halves for
-// the gate); wave w owns the 32-row block (8*blockIdx.y + w).  K-step = one 64-channel plane chunk: the B tile
+// plane GEMM.  Workgroup = 4 waves (one per SIMD, up to 512 registers each) = one tile of 32*CT consecutive rows of one
+// phase x 128 matrix rows (x 2 halves for the gate); wave w owns the 32-row block (4*blockIdx.y + w).  The tile is
+// WIDE (CT = 6: 192 columns) because every workgroup streams its rows of A out of L2 once per tile: with 8 waves x
+// 96 columns the gate GEMM was 36 % MFMA-busy and pulled 1.6 GB of weights per launch through L2 (11.7 TB/s); 192
+// columns x half the rows is 4x fewer A bytes per column.  K-step = one 64-channel plane chunk: the B tile
 // (128 rows x 128 B) goes global -> registers -> LDS (XOR-swizzled 16-byte pieces, double buffered, one barrier per
 // step); A comes in MFMA-fragment order [K-step][32-row block][sub-step s][lane][8] (wg_train.h), so a wave's load of
 // one fragment is one contiguous KiB; element j of lane (r, h) in sub-step s is k = 32h + 8s + j of the step, and the
@@ -54,18 +57,28 @@ __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, in
 // as both operands agree.  (Reading fragments straight from a row-major matrix -- 64 lanes on 64 different cache
 // lines per load -- ran the whole kernel at the L1's line rate: 2.5x slower.)
 // =============================================================================================
+// diagnostics (tools/stamp_train.py): when set, every gate-GEMM workgroup writes s_memtime at 4 phase boundaries
+static unsigned long long* g_pg_stamps = nullptr;
+void set_plane_gemm_stamps(unsigned long long* p) { g_pg_stamps = p; }
+
+constexpr int PG_WAVES = 4;
+constexpr int PG_THREADS = 64 * PG_WAVES;
+
 template <int EPI, int CT>
-__global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
+__global__ void __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2)))
+plane_gemm_kernel(const PGemmArgs a) {
   constexpr int MT = (EPI == EPI_GATE) ? 2 : 1;
-  constexpr int BN = 32 * CT;    // tile width in rows; the B staging always moves 128 rows (rows >= BN are unused)
-  __shared__ __attribute__((aligned(16))) _Float16 sB[2][128 * 64];
+  constexpr int BN = 32 * CT;    // tile width in rows = B-tile rows: CT 16-byte pieces per thread
+  __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * 64];
+  unsigned long long tstamp[4];
+  if (EPI == EPI_GATE && a.stamps) tstamp[0] = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const RowGeom& g = a.g;
   const int tpp = g.Rp / BN;
   const int tile = blockIdx.x;
   const int p = tile / tpp, r0 = (tile - p * tpp) * BN;
-  const int blk = blockIdx.y * 8 + w;
+  const int blk = blockIdx.y * PG_WAVES + w;
   const bool active = blk * 32 < a.M;
   const size_t R64 = (size_t)g.R * 64;
 
@@ -87,36 +100,35 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   int n_steps = 0;
   for (int i = 0; i < a.n_runs; ++i) n_steps += a.run[i].n_chunks;
 
-  // B-tile staging: thread -> pieces tid and tid + 512 of 1024 (row = idx >> 3, piece = idx & 7)
+  // B-tile staging: thread -> pieces tid + 256 q, q < CT (row = idx >> 3 = brow0 + 32 q, piece = idx & 7)
   const int brow0 = tid >> 3, bpc = tid & 7;
   // physical 16-byte piece = logical ^ ((row >> 1) & 7): a ds_read_b128 is served in four 16-lane groups
   // ({0-3,12-15,20-27}, ... MI355X_MICROARCH.md, LDS) over 64 banks = two rows; this key gives every group 16
   // distinct (row parity, piece) pairs.  (Keyed on row & 7 it was 2-way: 43 % of the LDS cycles were conflicts.)
-  const int bsw = (brow0 >> 1) & 7;                                    // same key for row brow0 + 64
+  const int bsw = (brow0 >> 1) & 7;                                    // same key for rows brow0 + 32 q
   const int lds_w0 = brow0 * 64 + ((bpc ^ bsw) << 3);
-  const int lds_w1 = (brow0 + 64) * 64 + ((bpc ^ bsw) << 3);
 
   // Prefetch distance TWO K-steps (one step of MFMAs is shorter than a loaded L2/HBM round trip when all 256 CUs
   // burst their tiles together): A fragments in a two-step register ring, every fragment refilled for step st+2
   // right after its last MFMA of step st; B in two register stages: fetched for st+2 at the top of step st,
   // committed to the other LDS buffer at the end of step st+1.  Waits are the compiler's (counted vmcnt); the
   // sched_barriers pin the issue order, which is what makes the counts come out as "wait for the oldest only".
-  half8 aring[2][MT][4], bst[2][2];
+  half8 aring[2][MT][4], bst[2][CT];
   int ri = 0, ci = 0;   // run / chunk of the next B tile to fetch (tiles are fetched in step order)
   // (the loop body is kept branch-free: hipcc's vmcnt bookkeeping turns conservative -- vmcnt(0) -- at every
   //  control-flow join, so past the last step the fetches simply repeat the last tile / fragment)
   auto fetch_b = [&](half8* dst) {
     const PRun& R = a.run[ri];
     const _Float16* src = R.base + (size_t)ci * R64 + (shifted_row(g, p, R.dt) + r0) * 64;
-    dst[0] = *(const half8*)(src + (size_t)brow0 * 64 + bpc * 8);
-    dst[1] = *(const half8*)(src + (size_t)(brow0 + 64) * 64 + bpc * 8);
+#pragma unroll
+    for (int q = 0; q < CT; ++q) dst[q] = *(const half8*)(src + (size_t)(brow0 + 32 * q) * 64 + bpc * 8);
     const bool last_chunk = ci + 1 == R.n_chunks, last_run = ri + 1 == a.n_runs;
     ci = last_chunk ? (last_run ? ci : 0) : ci + 1;
     ri = (last_chunk && !last_run) ? ri + 1 : ri;
   };
   auto commit_b = [&](int buf, const half8* srcr) {
-    *(half8*)&sB[buf][lds_w0] = srcr[0];
-    *(half8*)&sB[buf][lds_w1] = srcr[1];
+#pragma unroll
+    for (int q = 0; q < CT; ++q) *(half8*)&sB[buf][lds_w0 + 32 * 64 * q] = srcr[q];
   };
   auto fetch_a = [&](half8 (*dst)[4], int step) {
 #pragma unroll
@@ -132,6 +144,7 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
   fetch_a(aring[1], last < 1 ? last : 1);
   commit_b(0, bst[0]);
   __syncthreads();
+  if (EPI == EPI_GATE && a.stamps) tstamp[1] = __builtin_amdgcn_s_memtime();
 
   // waves without rows (M < 256 x MT) run the same instruction stream on block 0 and skip the epilogue
   auto body = [&](auto PAR, int st) {
@@ -139,17 +152,24 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
     const int st2 = st + 2 < last ? st + 2 : last;
     fetch_b(bst[par]);
     __builtin_amdgcn_sched_barrier(0);
+    // B fragments are read one sub-step ahead (one wave per SIMD: nobody else covers the LDS latency)
+    half8 bf[2][CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      bf[0][ct] = *(const half8*)&sB[par][(ct * 32 + r) * 64 + (((4 * h) ^ ((r >> 1) & 7)) << 3)];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      half8 bf[CT];
+      if (s < 3) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-        bf[ct] = *(const half8*)&sB[par][(ct * 32 + r) * 64 + (((4 * h + s) ^ ((r >> 1) & 7)) << 3)];
+        for (int ct = 0; ct < CT; ++ct)
+          bf[(s + 1) & 1][ct] = *(const half8*)&sB[par][(ct * 32 + r) * 64 + (((4 * h + s + 1) ^ ((r >> 1) & 7)) << 3)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
-          acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[par][mt][s], bf[ct], acc[mt][ct], 0, 0, 0);
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[par][mt][s], bf[s & 1][ct], acc[mt][ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -165,6 +185,7 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
     body(std::integral_constant<int, 1>{}, st + 1);
   }
   if (st < n_steps) body(std::integral_constant<int, 0>{}, st);
+  if (EPI == EPI_GATE && a.stamps) tstamp[2] = __builtin_amdgcn_s_memtime();
   if (!active) return;
 
   // ---- epilogue: lane (column r of column tile ct, half h) holds matrix positions P0 .. P0+15 of its 32-block
@@ -239,15 +260,21 @@ __global__ void __launch_bounds__(512) plane_gemm_kernel(const PGemmArgs a) {
       *(half8*)(a.o0 + addr_s) = gs0; *(half8*)(a.o0 + addr_s + 8) = gs1;
     }
   }
+  if (EPI == EPI_GATE && a.stamps && tid == 0) {
+    tstamp[3] = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    o[0] = tstamp[0]; o[1] = tstamp[1]; o[2] = tstamp[2]; o[3] = tstamp[3];
+  }
 }
 
 namespace {
 template <int EPI>
 void launch_pg(const PGemmArgs& a, int ct, hipStream_t s) {
-  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), (a.M + 255) / 256);
-  if (ct == 4) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 4>), grid, dim3(512), 0, s, a);
-  else if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 3>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((plane_gemm_kernel<EPI, 2>), grid, dim3(512), 0, s, a);
+  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), (a.M + 32 * PG_WAVES - 1) / (32 * PG_WAVES));
+  if (ct == 6) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 6>), grid, dim3(PG_THREADS), 0, s, a);
+  else if (ct == 4) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 4>), grid, dim3(PG_THREADS), 0, s, a);
+  else if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 3>), grid, dim3(PG_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((plane_gemm_kernel<EPI, 2>), grid, dim3(PG_THREADS), 0, s, a);
 }
 int device_cus() {
   static int n = 0;
@@ -261,21 +288,25 @@ int device_cus() {
 }
 }  // namespace
 
-// Tile width: one workgroup per CU (8 waves x ~250 VGPRs), so a launch runs in ceil(tiles / CUs) rounds; among the
-// widths that divide Rp pick the one with the least rounds x width (config 4: Rp = 2304 -> 576 tiles of 128 would
-// be 3 rounds at 75 % occupancy; 768 tiles of 96 are exactly 3 full rounds of 3/4 the work).
-int plane_gemm_tile_cols(const RowGeom& g) {
-  if (const char* e = getenv("WG_TRAIN_CT")) {      // tests: pin the tile width (2, 3 or 4 column tiles of 32)
+// Tile width: one workgroup per CU (4 waves x up to 512 registers), so a launch runs in ceil(workgroups / CUs)
+// rounds; among the widths that divide Rp pick the one with the least rounds x width, wider first (config 4, 256
+// channels: Rp = 2304 -> 384 tiles of 192 columns x 2 row groups = 768 workgroups = exactly 3 rounds on 256 CUs).
+int plane_gemm_tile_cols(const RowGeom& g, int m_groups) {
+  if (const char* e = getenv("WG_TRAIN_CT")) {      // tests: pin the tile width (2, 3, 4 or 6 column tiles of 32)
     const int ct = atoi(e);
-    if (ct >= 2 && ct <= 4 && g.Rp % (32 * ct) == 0) return ct;
+    if ((ct == 2 || ct == 3 || ct == 4 || ct == 6) && g.Rp % (32 * ct) == 0) return ct;
   }
   const int cus = device_cus();
+  static const int widths[4] = {6, 4, 3, 2};
   int best = 0;
   long long best_cost = 0;
-  for (int ct = 4; ct >= 2; --ct) {
+  for (int i = 0; i < 4; ++i) {
+    const int ct = widths[i];
     if (g.Rp % (32 * ct)) continue;
-    const long long tiles = (long long)kPhases * (g.Rp / (32 * ct));
-    const long long cost = ((tiles + cus - 1) / cus) * ct;
+    const long long wgs = (long long)kPhases * (g.Rp / (32 * ct)) * m_groups;
+    // rounds x width, plus 2.5 % per dropped column tile: a narrower tile re-reads the weights more often from L2
+    // (the K = 49152 cond_layer dgrad at 96 columns pulled 48 GB through L2 per launch)
+    const long long cost = ((wgs + cus - 1) / cus) * ct * (1000 + 25 * (6 - ct));
     if (!best || cost < best_cost) { best = ct; best_cost = cost; }
   }
   return best;
@@ -286,13 +317,15 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks * 64;
   if (k != a.ktot) return hipErrorInvalidValue;
-  const int ct = plane_gemm_tile_cols(a.g);
+  const int ct = plane_gemm_tile_cols(a.g, (a.M + 32 * PG_WAVES - 1) / (32 * PG_WAVES));
+  PGemmArgs b = a;
+  b.stamps = g_pg_stamps;
   switch (epi) {
     case EPI_STORE16:
-    case EPI_RES: launch_pg<EPI_RES>(a, ct, s); break;
-    case EPI_GATE: launch_pg<EPI_GATE>(a, ct, s); break;
-    case EPI_ES: launch_pg<EPI_ES>(a, ct, s); break;
-    case EPI_DGATE: launch_pg<EPI_DGATE>(a, ct, s); break;
+    case EPI_RES: launch_pg<EPI_RES>(b, ct, s); break;
+    case EPI_GATE: launch_pg<EPI_GATE>(b, ct, s); break;
+    case EPI_ES: launch_pg<EPI_ES>(b, ct, s); break;
+    case EPI_DGATE: launch_pg<EPI_DGATE>(b, ct, s); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

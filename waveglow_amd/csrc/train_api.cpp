@@ -135,6 +135,12 @@ PRun run_of(const _Float16* base, int n_chunks, int dt) {
 
 extern "C" {
 
+/* diagnostics (not in the public header): device buffer for the gate GEMM's phase stamps, see tools/stamp_train.py */
+int wg_train_debug_stamps(void* device_buffer) {
+  set_plane_gemm_stamps((unsigned long long*)device_buffer);
+  return WG_OK;
+}
+
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
   Ctx x;
   if (setup(const_cast<wg_handle*>(h), B, n_frames, audio_len, nullptr, 0, x) != WG_OK) return 0;

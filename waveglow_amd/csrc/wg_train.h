@@ -48,6 +48,7 @@ struct PGemmArgs {
   _Float16 *o0, *o1, *o2;   // output planes
   const _Float16 *i0, *i1;  // epilogue input planes
   float* rows32;            // EPI_ES: OUT [B*L][8]
+  unsigned long long* stamps;   // diagnostics only (set by the launcher from set_plane_gemm_stamps), else null
 };
 
 // dW[m][k'] = sum over the rows of one slab of G[row][m] * X[row(+shift)][k']  -> out[slab][m][k'] * out_scale
@@ -103,6 +104,7 @@ struct StartWgradArgs {
 };
 
 hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s);
+void set_plane_gemm_stamps(unsigned long long* device_buffer);   // diagnostics: [workgroups][4] s_memtime of the gate GEMM
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
