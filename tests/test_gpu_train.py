@@ -150,3 +150,33 @@ def test_backward_after_a_second_forward_raises():
   l2.backward()
   with pytest.raises((WgError, RuntimeError)):
     l2.backward()
+
+
+def test_gradient_allreduce_over_rccl_single_rank():
+  """The exchange step on the device: bucketed all-reduce through RCCL ("nccl") in a one-rank group leaves the
+  gradients of a real training step unchanged (the two-rank averaging itself is covered on CPU with gloo)."""
+  import socket
+  import torch.distributed as dist
+  from waveglow_amd.distributed import GradientAllReducer
+  over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 6, 2)
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
+  before = [p.grad.clone() for p in model.parameters()]
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                          device_id=torch.device("cuda:0"))
+  try:
+    red = GradientAllReducer(model.parameters(), bucket_bytes=1 << 20)
+    assert len(red.buckets) > 3
+    red.reduce(force=True)
+    torch.cuda.synchronize()
+  finally:
+    dist.destroy_process_group()
+  for a, p in zip(before, model.parameters()):
+    assert torch.equal(a, p.grad)

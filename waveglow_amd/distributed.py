@@ -38,12 +38,13 @@ class GradientAllReducer:
     return self._flat
 
   @torch.no_grad()
-  def reduce(self) -> None:
-    """Average ``p.grad`` over the process group, in place.  A parameter without a gradient counts as zero."""
+  def reduce(self, force: bool = False) -> None:
+    """Average ``p.grad`` over the process group, in place.  A parameter without a gradient counts as zero.
+    ``force`` runs the collective even in a one-rank group (tests of the RCCL path on a single GPU)."""
     if not dist.is_available() or not dist.is_initialized():
       return
     world = dist.get_world_size(self.group)
-    if world == 1:
+    if world == 1 and not force:
       return
     flats = self._buffers()
     views, works = [], []
