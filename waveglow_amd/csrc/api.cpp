@@ -87,6 +87,7 @@ constexpr float kSigmScale = -1.4426950408889634f;   // -log2(e)
 
 struct LayerOffsets {
   size_t wA1, bias1, wA2, bias2, wEs;
+  size_t wA1f = 0;   // layer 0 only: in_layers[0] o start folded onto the a0 plane, 3 K-steps
 };
 struct FlowOffsets {
   std::vector<LayerOffsets> layers;
@@ -112,6 +113,7 @@ struct wg_handle {
   std::vector<FlowOffsets> flows;
   int n_cu = 256;         // multiProcessorCount, read in wg_finalize
   int force_bn = 0;       // WG_FORCE_BN=64|128 (tests): pin the WN tile width instead of choosing by workload size
+  bool fold_start = true; // WG_NO_START_FOLD=1 (tests / A-B runs): first WN layer reads x_0 like every other layer
   unsigned long long* dbg_stamps = nullptr;   // diagnostic builds only
   // profiling
   bool prof = false;
@@ -150,10 +152,10 @@ RowGeom make_geom(const wg_config& c, int B, int L, int T) {
 }
 
 struct Workspace {
-  _Float16 *melT, *X0, *X1;
+  _Float16 *melT, *X0, *X1, *A0;
   float *Z, *OUT;
   size_t bytes;
-  size_t x_bytes, mel_bytes;
+  size_t x_bytes, mel_bytes, a0_bytes;
 };
 
 Workspace carve(const wg_handle* h, const RowGeom& g, char* base) {
@@ -165,6 +167,8 @@ Workspace carve(const wg_handle* h, const RowGeom& g, char* base) {
   w.melT = (_Float16*)(base + off); off += w.mel_bytes;
   w.X0 = (_Float16*)(base + off); off += w.x_bytes;
   w.X1 = (_Float16*)(base + off); off += w.x_bytes;
+  w.a0_bytes = align_up((size_t)g.R * 128);
+  w.A0 = (_Float16*)(base + off); off += w.a0_bytes;
   w.Z = (float*)(base + off); off += align_up((size_t)g.B * g.L * 8 * 4);
   w.OUT = (float*)(base + off); off += align_up((size_t)g.B * g.L * 8 * 4);
   w.bytes = off;
@@ -238,6 +242,7 @@ int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
   h->NS = c.n_mel_channels * c.n_group;
   h->c_k = ck;
   if (const char* e = getenv("WG_FORCE_BN")) h->force_bn = atoi(e);
+  if (const char* e = getenv("WG_NO_START_FOLD")) h->fold_start = !(*e == '1');
   h->expected.push_back("upsample.weight");
   h->expected.push_back("upsample.bias");
   for (int k = 0; k < c.n_flows; ++k) {
@@ -405,6 +410,38 @@ int wg_finalize(wg_handle* h) {
                   }
                 }
       }
+      if (i == 0) {
+        // in_layers[0] o start (model.py:117, :123): column kk of tap `tap` on the a0 plane row (a0 | 1 | 0...):
+        //   kk < h: sum_ch W_in[m][ch][tap] W_start[ch][kk];  kk == 4: sum_ch W_in[m][ch][tap] b_start[ch]
+        std::vector<double> fold((size_t)2 * C * 3 * 8, 0.0);
+        for (int m = 0; m < 2 * C; ++m)
+          for (int tap = 0; tap < 3; ++tap) {
+            double* fr = &fold[((size_t)m * 3 + tap) * 8];
+            for (int ch = 0; ch < C; ++ch) {
+              const double wv = win->data[((size_t)m * C + ch) * 3 + tap];
+              for (int j = 0; j < hk; ++j) fr[j] += wv * wst->data[(size_t)ch * hk + j];
+              fr[4] += wv * bst->data[ch];
+            }
+          }
+        lo.wA1f = reserve((size_t)3 * 2 * NW * MT * 2 * 64 * 8 * 2);
+        _Float16* dst = (_Float16*)(blob.data() + lo.wA1f);
+        for (int u = 0; u < 2 * 3; ++u)
+          for (int w = 0; w < NW; ++w)
+            for (int mt = 0; mt < MT; ++mt)
+              for (int k2 = 0; k2 < 2; ++k2)
+                for (int lane = 0; lane < 64; ++lane) {
+                  const int tap = u >> 1, k16 = (u & 1) * 2 + k2;
+                  const int r = lane & 31, hh = lane >> 5;
+                  const bool tanh_row = mt < MB;
+                  const int m = (tanh_row ? 0 : C) + 32 * (w * MB + (tanh_row ? mt : mt - MB)) + r;
+                  const float rs = tanh_row ? kTanhScale : kSigmScale;
+                  _Float16* d = dst + (((((size_t)u * NW + w) * MT + mt) * 2 + k2) * 64 + lane) * 8;
+                  for (int j = 0; j < 8; ++j) {
+                    const int kk = k16 * 16 + 8 * hh + j;          // channel of the a0 plane (natural order)
+                    d[j] = (_Float16)(kk < 8 ? (float)(fold[((size_t)m * 3 + tap) * 8 + kk] * rs) : 0.0f);
+                  }
+                }
+      }
       lo.bias1 = reserve((size_t)2 * C * 4);
       {
         float* b1 = (float*)(blob.data() + lo.bias1);
@@ -540,9 +577,12 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     WnLayerArgs a;
     a.x_in = cur;
     a.x_out = oth;
+    const bool fold0 = (i == 0) && h->fold_start;       // in_layers[0] o start on the a0 plane (3 K-steps)
+    a.x_tap = fold0 ? w.A0 : cur;
+    a.x_chunks_per_tap = fold0 ? 1 : C / 64;
     a.melT = w.melT;
     a.wA1c = (const _Float16*)(h->d_cond + h->cond_flow_bytes * k + h->cond_layer_bytes * i);
-    a.wA1 = (const _Float16*)(h->d_blob + lo.wA1);
+    a.wA1 = (const _Float16*)(h->d_blob + (fold0 ? lo.wA1f : lo.wA1));
     a.bias1 = (const float*)(h->d_blob + lo.bias1);
     a.wA2 = (const _Float16*)(h->d_blob + lo.wA2);
     a.bias2 = (const float*)(h->d_blob + lo.bias2);
@@ -590,7 +630,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
   {
     Prof p(h, s, 3);
     // guard rows / rows >= L of both x planes must read as zero padding (model.py:98-102)
-    HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes, s));
+    HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes + w.a0_bytes, s));
   }
   {
     MelPackArgs u;
@@ -631,6 +671,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
     f.bstart = (const float*)(h->d_blob + h->flows[k].bstart);
     f.out_init = (const float*)(h->d_blob + h->flows[k].out_init);
     f.x = cur;
+    f.a0p = w.A0;
     Prof p(h, s, 1);
     HIP_TRY(launch_flow(f, s));
   }
@@ -659,6 +700,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
       f.bstart = (const float*)(h->d_blob + h->flows[k - 1].bstart);
       f.out_init = (const float*)(h->d_blob + h->flows[k - 1].out_init);
       f.x = cur;
+      f.a0p = w.A0;
     }
     Prof p(h, s, 1);
     HIP_TRY(launch_flow(f, s));
@@ -687,7 +729,7 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_channels;
   for (int k = 0; k < c.n_flows; ++k) log_det_W[k] = (float)((double)B * L * h->flows[k].logdet);   // model.py:63
-  HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes, s));
+  HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes + w.a0_bytes, s));
   {
     MelPackArgs u;
     u.mel = mel;
@@ -736,6 +778,7 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
       f.bstart = (const float*)(h->d_blob + h->flows[k].bstart);
       f.out_init = (const float*)(h->d_blob + h->flows[k].out_init);
       f.x = cur;
+      f.a0p = w.A0;
       z_ch += f.n_peel;
     }
     {

@@ -112,13 +112,18 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // Wave w owns gate channels [32*MB*w, 32*MB*(w+1)): its A (weight) fragments are private, so they go L2 -> VGPR
 // directly (pre-packed in fragment order, 1 KiB per wave-load); the B tile (activations) is shared by all waves
 // and goes HBM/L2 -> LDS by LDS-DMA.  All VMEM of the K loop is hand-counted (see glds16).
-template <int C, int NW, int BN, bool HAS_RES, int TPW>
+// CX = 64-channel chunks per dilated tap of GEMM 1: C/64 normally; 1 for the FIRST layer of a WN, whose input
+// x_0 = start(a0) (model.py:117) is itself linear in the <= 4 coupling channels a0, so in_layers[0] o start collapses
+// to a [2C x (3 taps x 5)] matrix on the rows of the a0 plane (a0 | 1) that flow_kernel writes next to x_0:
+// 3 K-steps instead of 3C/64 (the bias of start rides on the constant-1 channel, which is 0 in the guard rows, so
+// the convolution's zero padding of x_0 stays exact).
+template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
   constexpr int MB = C / (32 * NW);      // 32-channel blocks per wave
   constexpr int MT = 2 * MB;             // M tiles per wave: MB tanh blocks, then MB sigmoid blocks
   constexpr int NTHREADS = NW * 64;
   constexpr int NT = BN / 32;            // 32-column MFMA tiles per wave
-  constexpr int CC = C / 64;             // 64-channel chunks of x
+  constexpr int CC = CX;                 // 64-channel chunks per tap of the GEMM-1 B operand (a.x_tap)
   constexpr int NKX = 3 * CC;            // K-steps of the three dilated taps
   constexpr int BT_BYTES = BN * 128;     // one staged B tile: BN rows x 64 fp16
   constexpr int ACT_ROW = 2 * C + 16;    // bytes per acts row: +16 B pad => conflict-free b128 reads/writes with
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int tap = ks / CC, cc = ks - tap * CC;
     const int pp = p + (tap - 1) * a.dil;
     const int row = kRowPad + (pp & 31) * Rp + jt * BN + (pp >> 5);
-    return (const char*)(a.x_in + ((size_t)cc * R + row) * 64);
+    return (const char*)(a.x_tap + ((size_t)cc * R + row) * 64);
   };
   // Conditioning K-step s (folded cond_layer o upsample, K = 4 taps x M mel channels): column n needs the mel
   // frames q-j, j = 0..3; k index = j*M + i.  Per-lane gather from the frame-major mel (mrow = melT row of the
@@ -587,13 +592,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   }
 }
 
-template <int C, int BN, bool HAS_RES, int TPW>
-static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
+template <int C, int BN, bool HAS_RES, int TPW, int CX>
+static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 2 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
@@ -601,8 +606,13 @@ static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
   // TPW tiles per workgroup: per XCD label ceil(tiles_on_label / TPW) blocks
   const int per_label = ((a.n_tiles + 7) / 8 + TPW - 1) / TPW;
   const int grid = 8 * per_label;
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW>), dim3(grid), dim3(NW * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
+}
+template <int C, int BN, bool HAS_RES, int TPW>
+static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
+  if (a.x_chunks_per_tap == 1) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
+  return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64>(a, s);
 }
 template <int C, int BN, bool HAS_RES>
 static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
@@ -884,6 +894,19 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
         op[0] = make_float4(a.out_init[0], a.out_init[1], a.out_init[2], a.out_init[3]);
         op[1] = make_float4(a.out_init[4], a.out_init[5], a.out_init[6], a.out_init[7]);
         s_a0[tid] = make_float4(zn[0], zn[1], zn[2], zn[3]);
+        if (a.a0p) {   // a0 plane for the folded first WN layer: (a0_0..a0_3 | 1 | 0 0 0), see wn_layer_kernel CX = 1
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+          const int hn = a.h_next;
+          o[0] = (_Float16)zn[0];
+          if (hn > 1) o[1] = (_Float16)zn[1];
+          if (hn > 2) o[2] = (_Float16)zn[2];
+          if (hn > 3) o[3] = (_Float16)zn[3];
+          o[4] = (_Float16)1.0f;
+          const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
+          *(half8*)(a.a0p + prow * 64) = o;
+        }
       }
     }
   }

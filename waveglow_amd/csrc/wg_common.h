@@ -54,6 +54,9 @@ constexpr int kPhases = 32;
 
 struct WnLayerArgs {
   const _Float16* x_in;     // [C/64][R][64] position-major
+  const _Float16* x_tap;    // B operand of the three dilated taps of GEMM 1: x_in, or for the first layer of a WN the
+                            // a0 plane [1][R][64] = (a0_0..a0_3, 1, 0...) with in_layers[0] o start folded into wA1
+  int x_chunks_per_tap;     // C/64, or 1 with the a0 plane
   _Float16* x_out;          // same layout (ping-pong), unused when !has_res
   const _Float16* melT;     // [3 + B*(3+T+3)][M] fp16 frame-major mel (3 zero rows of slack, then per utterance
                             // 3 zero rows, T frames, 3 zero rows)
@@ -111,6 +114,7 @@ struct FlowArgs {
   float* Z_w;               // where the new state / re-initialised out are written: = Z / out for inference (in place);
   float* out_w;             // the training forward keeps every flow's state and gives each flow its own buffers
   _Float16* x;              // [C/64][R][64] start output
+  _Float16* a0p;            // [1][R][64] a0 plane: channels 0..3 = a0 (fp16), channel 4 = 1, rest 0 (or null)
   void* audio_out;          // infer+last: [B][8L] io dtype
   RowGeom g;
   int C;
