@@ -133,23 +133,29 @@ def test_train_step_every_tile_width(ct, monkeypatch):
   _check(grads, g_ref, "ct" + ct)
 
 
-def test_backward_after_a_second_forward_raises():
-  """One training workspace per model: a second forward() overwrites the saved activations, so the first graph's
-  backward must fail loudly instead of producing gradients from the wrong activations."""
+def test_two_forwards_before_backward_and_double_backward():
+  """Gradient accumulation pattern: forward, forward, backward, backward -- the second forward gets its own training
+  workspace, so both graphs back-propagate correctly (sum of the two gradients = 2x the single-step gradient for the
+  same batch); a second backward through the same graph fails loudly (the activations are released)."""
   from waveglow_amd._lib import WgError
   over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
   hp, sd, mel, wav = _setup(over, 2, 6, 2)
+  _, _, single = _gpu_step(hp, sd, mel, wav)
   model = WaveGlow(hp)
   model.load_state_dict(sd)
   model = model.to("cuda:0").train()
   crit = WaveGlowLoss(1.0)
   l1 = crit(model((mel.cuda(), wav.cuda())), None)
   l2 = crit(model((mel.cuda(), wav.cuda())), None)
-  with pytest.raises(WgError):
-    l1.backward()
+  l1.backward()
   l2.backward()
+  torch.cuda.synchronize()
+  for name, p in model.named_parameters():
+    ref = 2.0 * single[name]
+    assert float((p.grad.cpu() - ref).norm()) <= 1e-5 * float(ref.norm()) + 1e-9, name
   with pytest.raises((WgError, RuntimeError)):
     l2.backward()
+  assert len(model._engine._train_pool) == 2 and not any(e["busy"] for e in model._engine._train_pool)
 
 
 def test_gradient_allreduce_over_rccl_single_rank():

@@ -344,11 +344,13 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
 // =============================================================================================
 constexpr int WG_GS = 288;      // LDS row stride of the G tile in halves (4 chunks + pad)
 constexpr int WG_XS = 160;      // ... of the X tile (2 chunks + pad)
-constexpr int WG_STEP = 32;     // rows per step
+constexpr int WG_STEP = 32;     // rows per step (64-row steps -- 16 MFMAs between barriers, 112 KB of LDS -- measured 10 % slower)
+constexpr int WG_LDS_BYTES = 2 * WG_STEP * (WG_GS + WG_XS) * 2;   // 57 344 B, dynamic
 
 __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 sG[2][WG_STEP * WG_GS];
-  __shared__ __attribute__((aligned(16))) _Float16 sX[2][WG_STEP * WG_XS];
+  extern __shared__ __attribute__((aligned(16))) _Float16 wg_smem[];
+  _Float16* const sG[2] = {wg_smem, wg_smem + WG_STEP * WG_GS};
+  _Float16* const sX[2] = {wg_smem + 2 * WG_STEP * WG_GS, wg_smem + 2 * WG_STEP * WG_GS + WG_STEP * WG_XS};
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wk = w & 1;
   const RowGeom& g = a.g;
@@ -358,8 +360,8 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   const int mc0 = blockIdx.x * 4, kc0 = blockIdx.y * 2;
   const size_t R64 = (size_t)g.R * 64;
 
-  // staging.  G: pieces tid, tid + 512 of 1024: row = (tid >> 5) + 16 q, chunk e = (tid >> 3) & 3, piece = tid & 7
-  //           X: piece tid of 512: row = tid >> 4, chunk e = (tid >> 3) & 1, piece = tid & 7
+  // staging.  G: pieces tid + 512 q (q < WG_STEP/16): row = (tid >> 5) + 16 q, chunk e = (tid >> 3) & 3, piece = tid & 7
+  //           X: pieces tid + 512 q (q < WG_STEP/32): row = (tid >> 4) + 32 q, chunk e = (tid >> 3) & 1, piece = tid & 7
   const int grow = tid >> 5, ge = (tid >> 3) & 3, xrow = tid >> 4, xe = (tid >> 3) & 1, spc = tid & 7;
   const int gch = (mc0 + ge < a.m_chunks) ? mc0 + ge : a.m_chunks - 1;
   const _Float16* gsrc = a.G + (size_t)gch * R64 + ((size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + grow) * 64 + spc * 8;
@@ -391,17 +393,20 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) accb[i][j] = 0.0f;
 
-  half8 gst[2][2], xst[2];
+  constexpr int GQ = WG_STEP / 16, XQ = WG_STEP / 32;
+  half8 gst[2][GQ], xst[2][XQ];
   auto fetch = [&](int par, int st) {
     const size_t ro = (size_t)st * WG_STEP * 64;
-    gst[par][0] = *(const half8*)(gsrc + ro);
-    gst[par][1] = *(const half8*)(gsrc + ro + 16 * 64);
-    xst[par] = *(const half8*)(xsrc + ro);
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) gst[par][q] = *(const half8*)(gsrc + ro + (size_t)q * 16 * 64);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) xst[par][q] = *(const half8*)(xsrc + ro + (size_t)q * 32 * 64);
   };
   auto commit = [&](int buf, int par) {
-    *(half8*)&sG[buf][lds_g] = gst[par][0];
-    *(half8*)&sG[buf][lds_g + 16 * WG_GS] = gst[par][1];
-    *(half8*)&sX[buf][lds_x] = xst[par];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) *(half8*)&sG[buf][lds_g + q * 16 * WG_GS] = gst[par][q];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) *(half8*)&sX[buf][lds_x + q * 32 * WG_XS] = xst[par][q];
   };
 
   // transposing fragment read: lane = 16*g16 + u; MFMA operand lane (r = lane & 31, hh = lane >> 5) needs rows
@@ -488,46 +493,61 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks;
   if (k != a.k_chunks || a.m_chunks < 1) return hipErrorInvalidValue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
   dim3 grid((a.m_chunks + 3) / 4, (a.k_chunks + 1) / 2, kPhases * a.row_split);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(512), 0, s, a);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(512), WG_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
-// out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads, four
-// independent partial sums so that four slab reads are in flight per thread.
+// out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads; a workgroup is
+// 64 float4 columns x 4 slab groups (thread (x, y) sums slabs y, y+4, ... with two independent partial sums), then the
+// four groups are combined through LDS in a fixed order -- 8 slab reads in flight per element instead of a serial chain.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, size_t stride,
                                                           size_t n, float scale, float* __restrict__ out) {
+  __shared__ float4 part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const size_t n4 = n >> 2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 acc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = 0;
-    for (; k + 4 <= n_slabs; k += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 v = *(const float4*)(slabs + (size_t)(k + u) * stride + 4 * i);
-        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+  for (size_t base = (size_t)blockIdx.x * 64; base < n4; base += (size_t)gridDim.x * 64) {
+    const size_t i = base + tx;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (i < n4) {
+      int k = ty;
+      for (; k + 4 < n_slabs; k += 8) {
+        const float4 u = *(const float4*)(slabs + (size_t)k * stride + 4 * i);
+        const float4 v = *(const float4*)(slabs + (size_t)(k + 4) * stride + 4 * i);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+      }
+      if (k < n_slabs) {
+        const float4 u = *(const float4*)(slabs + (size_t)k * stride + 4 * i);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
       }
     }
-    for (; k < n_slabs; ++k) {
-      const float4 v = *(const float4*)(slabs + (size_t)k * stride + 4 * i);
-      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    part[ty][tx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (ty == 0 && i < n4) {
+      const float4 p0 = part[0][tx], p1 = part[1][tx], p2 = part[2][tx], p3 = part[3][tx];
+      float4 o;
+      o.x = ((p0.x + p1.x) + (p2.x + p3.x)) * scale;
+      o.y = ((p0.y + p1.y) + (p2.y + p3.y)) * scale;
+      o.z = ((p0.z + p1.z) + (p2.z + p3.z)) * scale;
+      o.w = ((p0.w + p1.w) + (p2.w + p3.w)) * scale;
+      *(float4*)(out + 4 * i) = o;
     }
-    float4 o;
-    o.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) * scale;
-    o.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) * scale;
-    o.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) * scale;
-    o.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) * scale;
-    *(float4*)(out + 4 * i) = o;
+    __syncthreads();
   }
 }
 
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
                               hipStream_t s) {
   if ((n & 3) || (stride & 3)) return hipErrorInvalidValue;
-  size_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  size_t blocks = (n / 4 + 63) / 64;
+  if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, n_slabs, stride, n, scale, out);
   return hipGetLastError();

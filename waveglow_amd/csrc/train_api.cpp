@@ -293,7 +293,7 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
   const int cc = C / 64, mc = M8 / 64;
   const float inv = 1.0f / scale;
   // the C x C and 64 x C weight gradients have few output tiles: cut every phase's rows into parts (more slabs)
-  const int small_split = (g.Rp % (4 * 32) == 0) ? 4 : 1;
+  const int small_split = 4;                           // Rp is a multiple of 128 = 4 parts of whole 32-row steps
   const _Float16* wat = (const _Float16*)wt->wat;
   const _Float16* wbt = (const _Float16*)wt->wbt;
 

@@ -79,7 +79,6 @@ class _Engine:
     self.device = device
     self.signature: Optional[tuple] = None
     self._ws: Dict[Tuple[str, int, int, int], torch.Tensor] = {}
-    self._train_ws: Optional[Tuple[Tuple[int, int, int], torch.Tensor]] = None
 
   def __del__(self):
     try:
@@ -109,15 +108,20 @@ class _Engine:
     return ws
 
 
-  def train_workspace(self, nbytes: int, key: Tuple[int, int, int]) -> Tuple[torch.Tensor, bool]:
-    """Workspace of the training direction (saved activations); ``fresh`` tells the library to clear it: its guard
-    rows must read as zero and stay so, which holds as long as the geometry ``key`` does not change."""
-    if self._train_ws is not None and self._train_ws[0] == key and self._train_ws[1].numel() >= nbytes:
-      return self._train_ws[1], False
-    self._train_ws = None
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-    self._train_ws = (key, ws)
-    return ws, True
+  def train_workspace(self, nbytes: int, key: Tuple[int, int, int]) -> Tuple[dict, bool]:
+    """A workspace of the training direction (saved activations) that no pending backward still needs.
+    ``fresh`` tells the library to clear it (guard rows must read as zero; they stay zero as long as the geometry
+    ``key`` does not change).  Normally there is exactly one; a second forward() before the first backward()
+    (gradient accumulation over micro-batches, two losses) gets another one instead of clobbering the first."""
+    pool = self.__dict__.setdefault("_train_pool", [])
+    pool[:] = [e for e in pool if e["key"] == key and e["ws"].numel() >= nbytes]   # geometry changed: drop the old ones
+    for e in pool:
+      if not e["busy"]:
+        e["busy"] = True
+        return e, False
+    e = {"key": key, "ws": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "busy": True}
+    pool.append(e)
+    return e, True
 
 
 class WaveGlow(nn.Module):

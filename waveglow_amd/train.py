@@ -32,6 +32,17 @@ def pos_perm(n: int) -> torch.Tensor:
   return blk * 32 + 8 * g + 4 * h + i
 
 
+_PERM_CACHE: dict = {}
+
+
+def _perms(Cc: int, M8: int, device) -> "_Perms":
+  """Index tensors are built (and copied to the device) once per geometry, not once per step."""
+  key = (Cc, M8, str(device))
+  if key not in _PERM_CACHE:
+    _PERM_CACHE[key] = _Perms(Cc, M8, device)
+  return _PERM_CACHE[key]
+
+
 class _Perms:
   def __init__(self, Cc: int, M8: int, device):
     pc = pos_perm(Cc)
@@ -40,6 +51,8 @@ class _Perms:
     self.m8 = pos_perm(M8).to(device)
     self.k1 = torch.cat([pc, Cc + pc, 2 * Cc + pc, 3 * Cc + pos_perm(M8)]).to(device)
     self.r32 = pos_perm(32).to(device)
+    r = torch.arange(32)
+    self.c2p = (16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)).to(device)   # chan_to_pos inside a 32-block
 
 
 def pack_weights(model) -> Tuple[torch.Tensor, ...]:
@@ -47,7 +60,7 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
   hp = model._hp
   Cc, nl, nf, M, M8 = hp.n_channels, hp.n_layers, model.n_flows, hp.n_mel_channels, hp.n_mel_channels * 8
   dev = model.upsample.weight.device
-  pm = _Perms(Cc, M8, dev)
+  pm = _perms(Cc, M8, dev)
   w_in, b_in, w_cond, b_cond, w_res, b_res, w_es, start5, out_init, w1x1 = [], [], [], [], [], [], [], [], [], []
   for k in range(nf):
     wn = model.WN[k]
@@ -95,12 +108,13 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
           torch.stack(w1x1).contiguous())
 
 
-def to_fragments(mat: torch.Tensor) -> torch.Tensor:
+def to_fragments(mat: torch.Tensor, c2p: torch.Tensor = None) -> torch.Tensor:
   """[..., M, K] (pos,pos) fp16 -> MFMA-fragment order [..., K/64, M/32, 4, 64, 8] (wg_train.h: PGemmArgs::A):
   lane (r, h), element j of sub-step s of block b, K-step t = mat[32b + chan_to_pos(r)][64t + 32h + 8s + j]."""
   *lead, M, K = mat.shape
-  r = torch.arange(32)
-  c2p = (16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)).to(mat.device)
+  if c2p is None:
+    r = torch.arange(32)
+    c2p = (16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)).to(mat.device)
   v = mat.reshape(*lead, M // 32, 32, K // 64, 2, 4, 8).index_select(len(lead) + 1, c2p)   # [.., b, r, t, h, s, j]
   n = len(lead)
   return v.permute(*range(n), n + 2, n, n + 4, n + 3, n + 1, n + 5).contiguous()            # [.., t, b, s, h, r, j]
@@ -119,19 +133,20 @@ class _Weights:
     Cc, nf = hp.n_channels, model.n_flows
     FL = w1.shape[0]
     dev = w1.device
-    r32 = pos_perm(32).to(dev)
+    pm = _perms(Cc, hp.n_mel_channels * 8, dev)
+    r32, c2p = pm.r32, pm.c2p
     w1h, w2h = w1.half(), w2.half()
     self.b1, self.b2, self.bup = b1.float(), b2.float(), bup.float()
     hi = wes.half()
     lo = (wes - hi.float()).half()
     nat = torch.cat([hi, lo, torch.zeros_like(hi), torch.zeros_like(hi)], 1)     # natural MFMA rows 0..31
-    self.w1 = to_fragments(w1h)
-    self.w2 = to_fragments(w2h)
-    self.wes = to_fragments(nat[:, r32])                   # matrix row chan_to_pos(r) holds MFMA row r
-    self.wat = to_fragments(torch.cat([w2h.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2))
-    self.wbt = to_fragments(torch.cat([w1h[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2))
-    self.wct = to_fragments(w1h[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc))
-    self.wup = to_fragments(wup.half())
+    self.w1 = to_fragments(w1h, c2p)
+    self.w2 = to_fragments(w2h, c2p)
+    self.wes = to_fragments(nat[:, r32], c2p)                   # matrix row chan_to_pos(r) holds MFMA row r
+    self.wat = to_fragments(torch.cat([w2h.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2), c2p)
+    self.wbt = to_fragments(torch.cat([w1h[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2), c2p)
+    self.wct = to_fragments(w1h[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc), c2p)
+    self.wup = to_fragments(wup.half(), c2p)
     self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
     self.bstart = [start5[k, 4].contiguous().float() for k in range(nf)]
     self.out_init = [out_init[k].contiguous().float() for k in range(nf)]
@@ -159,14 +174,13 @@ class _TrainFn(torch.autograd.Function):
     nbytes = lib.wg_train_workspace_bytes(eng.handle, B, F_, S)
     if nbytes == 0:
       raise _lib.WgError(lib.wg_last_error().decode())
-    ws, fresh = eng.train_workspace(nbytes, (B, F_, S))
-    eng.train_generation = getattr(eng, "train_generation", 0) + 1    # the workspace now holds THIS forward's activations
+    slot, fresh = eng.train_workspace(nbytes, (B, F_, S))             # held until this graph's backward has run
+    ws = slot["ws"]
     ls = (C.c_void_p * len(log_s))(*[t.data_ptr() for t in log_s])
     stream = torch.cuda.current_stream(mel.device).cuda_stream
     _lib.check(lib.wg_train_forward(eng.handle, C.byref(wts.struct), _ptr(mel), _ptr(audio), _ptr(z), ls, B, F_, S,
                                     1 if fresh else 0, _ptr(ws), ws.numel(), C.c_void_p(stream)))
-    ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio = model, wts, ws, (B, F_, S), audio
-    ctx.generation = eng.train_generation
+    ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio, ctx.slot = model, wts, ws, (B, F_, S), audio, slot
     ctx.scale = float(scale) if scale else float(2.0 ** round(math.log2(z.numel())))
     ctx.shapes = [t.shape for t in packed]
     return (z, *log_s)
@@ -176,9 +190,9 @@ class _TrainFn(torch.autograd.Function):
     model, wts = ctx.model, ctx.wts
     eng = model._engine
     lib = eng.lib
-    if ctx.wts is None or ctx.generation != eng.train_generation:
-      raise _lib.WgError("the saved activations of this forward pass are gone (backward already ran, or a later "
-                         "forward() reused the training workspace): call backward() once, before the next forward()")
+    if ctx.wts is None:
+      raise _lib.WgError("the saved activations of this forward pass are gone: backward() already ran for it "
+                         "(retain_graph is not supported by the training direction)")
     B, F_, S = ctx.dims
     dev = ctx.audio.device
     nf = model.n_flows
@@ -196,6 +210,7 @@ class _TrainFn(torch.autograd.Function):
                                      _ptr(gz) if gz is not None else None, gl_arr, C.c_float(ctx.scale),
                                      _ptr(ctx.audio), B, F_, S, _ptr(ctx.ws), ctx.ws.numel(), C.c_void_p(stream)))
     ctx.wts = None
+    ctx.slot["busy"] = False          # stream-ordered: the next forward's kernels queue behind this backward
     return (None, None, None, None, *grads)
 
 
