@@ -68,7 +68,7 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
     w_end = wn.end.weight[:, :, 0]                                   # [2h, C]
     cw = wn.cond_layer.weight[:, :, 0].view(nl, 2 * Cc, M8)
     cb = wn.cond_layer.bias.view(nl, 2 * Cc)
-    b_skip_sum = 0
+    w_skips, b_skips = [], []
     for i in range(nl):
       w_in.append(wn.in_layers[i].weight)                            # [2C, C, 3]
       b_in.append(wn.in_layers[i].bias + cb[i])
@@ -78,15 +78,16 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
       if i < nl - 1:                                                  # model.py:131-134
         w_res.append(rs_w[:Cc])
         b_res.append(rs_b[:Cc])
-        w_skip, b_skip = rs_w[Cc:], rs_b[Cc:]
+        w_skips.append(rs_w[Cc:])
+        b_skips.append(rs_b[Cc:])
       else:                                                           # model.py:135-136
         w_res.append(torch.zeros_like(rs_w[:Cc]))
         b_res.append(torch.zeros_like(rs_b[:Cc]))
-        w_skip, b_skip = rs_w, rs_b
-      es = w_end @ w_skip                                             # end(sum_i skip_i): [2h, C]
-      w_es.append(torch.nn.functional.pad(es, (0, 0, 0, 8 - h2)))
-      b_skip_sum = b_skip_sum + b_skip
-    out_init.append(torch.nn.functional.pad(w_end @ b_skip_sum + wn.end.bias, (0, 8 - h2)))
+        w_skips.append(rs_w)
+        b_skips.append(rs_b)
+    es = torch.matmul(w_end, torch.stack(w_skips))                    # end(sum_i skip_i): [nl, 2h, C], one batched GEMM
+    w_es.append(torch.nn.functional.pad(es, (0, 0, 0, 8 - h2)))
+    out_init.append(torch.nn.functional.pad(w_end @ torch.stack(b_skips).sum(0) + wn.end.bias, (0, 8 - h2)))
     ws = wn.start.weight[:, :, 0]                                     # [C, h]
     s5 = torch.cat([torch.nn.functional.pad(ws, (0, 4 - ws.shape[1])).t(), wn.start.bias[None, :]], 0)   # [5, C]
     start5.append(s5[:, pm.c])
@@ -98,7 +99,7 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
   b1 = torch.stack(b_in)[:, pm.c2]
   w2 = torch.stack(w_res)[:, pm.c][:, :, pm.c]
   b2 = torch.stack(b_res)[:, pm.c]
-  wes = torch.stack(w_es)[:, :, pm.c]                                           # [FL, 8, C]
+  wes = torch.cat(w_es)[:, :, pm.c]                                             # [FL, 8, C]
   up = model.upsample.weight                                                    # [M_in, M_out, 1024]
   wup = up.view(M, M, 4, 32, 8).permute(3, 1, 4, 2, 0).reshape(32, M8, 4, M)    # [p][(o,g)][j][i]
   wup = torch.nn.functional.pad(wup, (0, 128 - M)).reshape(32, M8, 512)[:, pm.m8]
