@@ -16,7 +16,7 @@ lib = os.path.join(ROOT, "gpurun_out", "libwaveglow_amd_stamps.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 extra = [f for f in sys.argv[2:] if f.startswith("-D") and f != "-DNONE"]
 subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-                "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "api.cpp"], cwd=csrc, check=True)
+                "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "stft.hip", "train.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"], cwd=csrc, check=True)
 os.environ["WAVEGLOW_AMD_LIB"] = lib
 
 import torch  # noqa: E402
