@@ -186,3 +186,39 @@ def test_gradient_allreduce_over_rccl_single_rank():
     dist.destroy_process_group()
   for a, p in zip(before, model.parameters()):
     assert torch.equal(a, p.grad)
+
+
+def test_full_size_directional_derivative_and_forward_consistency():
+  """BASELINE configs[3] shapes (256 channels, 16 000-sample segments; batch 8 to keep the test short), where no CPU
+  oracle finishes in seconds: size-independent checks.  (1) the training forward (saved activations, unfolded cond
+  path) and the inference-style forward (folded weights, wn_layer_kernel) agree on the loss; (2) the gradient of the
+  library's backward predicts the central finite difference of that loss along the gradient direction."""
+  hp, sd, mel, wav = _setup(dict(), 8, 63, 7, crop=256 * 63 - 16000)
+  assert wav.shape == (8, 16000)
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  crit = WaveGlowLoss(1.0)
+  mel_d, wav_d = mel.cuda(), wav.cuda()
+  loss = crit(model((mel_d, wav_d)), None)
+  loss.backward()
+  grads = [p.grad.detach().clone() for p in model.parameters()]
+  gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+  assert np.isfinite(gnorm) and gnorm > 0
+
+  def loss_at(eps):
+    with torch.no_grad():
+      for p, g in zip(model.parameters(), grads):
+        p.add_(g, alpha=eps / gnorm)
+      val = float(crit(model((mel_d, wav_d)), None))      # no-grad path: wg_forward on re-derived (folded) weights
+      for p, g in zip(model.parameters(), grads):
+        p.sub_(g, alpha=eps / gnorm)
+    return val
+
+  l0 = loss_at(0.0)
+  print(f"loss train-forward {float(loss.detach()):.6f}  inference-forward {l0:.6f}  |grad| {gnorm:.4e}")
+  assert abs(l0 - float(loss.detach())) <= 2e-4 * max(1.0, abs(l0))
+  eps = 0.02 / gnorm if gnorm > 1 else 0.02                 # a step that changes the loss by about 0.02 * |grad|
+  fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
+  print(f"directional derivative: finite difference {fd:.5e}  vs  |grad| {gnorm:.5e}")
+  assert abs(fd - gnorm) <= 0.03 * gnorm
