@@ -222,3 +222,15 @@ def test_full_size_directional_derivative_and_forward_consistency():
   fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
   print(f"directional derivative: finite difference {fd:.5e}  vs  |grad| {gnorm:.5e}")
   assert abs(fd - gnorm) <= 0.03 * gnorm
+
+
+@pytest.mark.parametrize("channels", [128, 512])
+def test_train_step_other_widths(channels):
+  """128 and 512 channels (1 and 4 row groups of the plane GEMM, 2 / 8 weight-gradient row tiles), small depth."""
+  from oracle import torch_oracle as O
+  over = dict(n_channels=channels, n_layers=2, n_flows=2, n_early_every=1, n_early_size=2)
+  hp, sd, mel, wav = _setup(over, 2, 7, 13, crop=24)
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check(grads, g_ref, f"c{channels}")
