@@ -45,7 +45,7 @@ def _gpu_step(hp, sd, mel, wav, sigma=1.0):
   loss.backward()
   torch.cuda.synchronize()
   grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
-  return float(loss), y, grads
+  return float(loss.detach()), y, grads
 
 
 def _check(grads, ref, what):
