@@ -156,6 +156,11 @@ def test_two_forwards_before_backward_and_double_backward():
   with pytest.raises((WgError, RuntimeError)):
     l2.backward()
   assert len(model._engine._train_pool) == 2 and not any(e["busy"] for e in model._engine._train_pool)
+  # a graph that is dropped without backward() (loss only logged) gives its workspace back as well
+  for _ in range(3):
+    l3 = crit(model((mel.cuda(), wav.cuda())), None)
+    del l3
+  assert len(model._engine._train_pool) == 2 and not any(e["busy"] for e in model._engine._train_pool)
 
 
 def test_gradient_allreduce_over_rccl_single_rank():

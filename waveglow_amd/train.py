@@ -160,6 +160,29 @@ class _Weights:
                                       C.cast(self._arrs[2], C.c_void_p), C.cast(self._arrs[3], C.c_void_p))
 
 
+class _SlotGuard:
+  """Returns a training workspace to the pool when its autograd graph goes away -- after backward(), or when the
+  graph is dropped without one (a loss that is only logged): otherwise every such forward would pin another workspace."""
+
+  _serial = 0
+
+  def __init__(self, slot: dict):
+    _SlotGuard._serial += 1
+    self.slot, self.token = slot, _SlotGuard._serial
+    slot["owner"] = self.token        # a number, not a reference: the guard must die with its graph
+
+  def release(self) -> None:
+    if self.slot.get("owner") == self.token:
+      self.slot["owner"] = None
+      self.slot["busy"] = False          # stream-ordered: the next forward's kernels queue behind pending work
+
+  def __del__(self):
+    try:
+      self.release()
+    except Exception:
+      pass
+
+
 class _TrainFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, model, mel, audio, scale, *packed):
@@ -181,7 +204,7 @@ class _TrainFn(torch.autograd.Function):
     stream = torch.cuda.current_stream(mel.device).cuda_stream
     _lib.check(lib.wg_train_forward(eng.handle, C.byref(wts.struct), _ptr(mel), _ptr(audio), _ptr(z), ls, B, F_, S,
                                     1 if fresh else 0, _ptr(ws), ws.numel(), C.c_void_p(stream)))
-    ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio, ctx.slot = model, wts, ws, (B, F_, S), audio, slot
+    ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio, ctx.guard = model, wts, ws, (B, F_, S), audio, _SlotGuard(slot)
     ctx.scale = float(scale) if scale else float(2.0 ** round(math.log2(z.numel())))
     ctx.shapes = [t.shape for t in packed]
     return (z, *log_s)
@@ -211,7 +234,7 @@ class _TrainFn(torch.autograd.Function):
                                      _ptr(gz) if gz is not None else None, gl_arr, C.c_float(ctx.scale),
                                      _ptr(ctx.audio), B, F_, S, _ptr(ctx.ws), ctx.ws.numel(), C.c_void_p(stream)))
     ctx.wts = None
-    ctx.slot["busy"] = False          # stream-ordered: the next forward's kernels queue behind this backward
+    ctx.guard.release()
     return (None, None, None, None, *grads)
 
 
