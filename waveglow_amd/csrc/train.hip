@@ -334,18 +334,22 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
 // =============================================================================================
 // Weight gradient.  out[slab][m][k'] = sum_rows G[row][m] X[row + shift][k'] over the rows of one slab (a phase, or
 // 1/row_split of a phase).  Workgroup = 8 waves = a 256 (m) x 128 (k') output tile; wave (wm, wk) owns a 64 x 64
-// quadrant.  Both operands are [row][channel] planes and the contraction runs over ROWS, so an MFMA fragment
-// (8 consecutive k = rows, one channel per lane) is a column of the LDS tile: fetched with ds_read_b64_tr_b16, which
-// hands lane i of a 16-lane group column i of a 4-row x 16-column block (cdna_hip_programming.md T10).  LDS rows are
-// padded (+64 B) so that the 4 rows x 64 B a 32-lane half touches fall on 64 distinct banks.
+// quadrant as 4 x 4 MFMA tiles of 16 x 16.  Both operands are [row][channel] planes and the contraction runs over
+// ROWS, so an MFMA fragment (8 k = rows, one channel per lane) is a column of the LDS tile: fetched with
+// ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4-row x 16-column block
+// (cdna_hip_programming.md T10).
 // Register-staged tiles two steps ahead, branch-free loop (see plane_gemm_kernel).  Chunks past the end of an operand
 // are clamped to its last chunk: their products are computed and never stored.
 // Guard / invalid rows of G are zero by construction (every producer writes zeros there), so no row masking.
 // =============================================================================================
-constexpr int WG_GS = 288;      // LDS row stride of the G tile in halves (4 chunks + pad)
-constexpr int WG_XS = 160;      // ... of the X tile (2 chunks + pad)
+// v_mfma_f32_16x16x32_f16 (one MFMA spans the 32 rows of a step; same-box A/B against the 32x32x16 version of this
+// kernel: 10 % faster at equal MFMA cycles -- the chip holds a higher clock with the 16x16 shape).  Lane group g reads
+// rows 4g..4g+3 and 16+4g..16+4g+3, so a 32-lane half touches 8 consecutive rows x 32 B: row strides of 32 B
+// (mod 256 B) are conflict-free.
+constexpr int WG_GS = 272;      // LDS row stride of the G tile in halves (4 chunks + 32 B)
+constexpr int WG_XS = 144;      // ... of the X tile (2 chunks + 32 B)
 constexpr int WG_STEP = 32;     // rows per step (64-row steps -- 16 MFMAs between barriers, 112 KB of LDS -- measured 10 % slower)
-constexpr int WG_LDS_BYTES = 2 * WG_STEP * (WG_GS + WG_XS) * 2;   // 57 344 B, dynamic
+constexpr int WG_LDS_BYTES = 2 * WG_STEP * (WG_GS + WG_XS) * 2;   // 53 248 B, dynamic
 
 __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 wg_smem[];
@@ -375,24 +379,21 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   const int lds_g = grow * WG_GS + ge * 64 + spc * 8;
   const int lds_x = xrow * WG_XS + xe * 64 + spc * 8;
 
-  f32x16 acc[2][2];
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v acc[4][4], accb[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[i][k][j] = 0.0f;
-  // bias gradient = row sums of G: the waves of the first k' tile also multiply their G fragments by a ones matrix
+      for (int j = 0; j < 4; ++j) acc[i][k][j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[i][j] = 0.0f;
+  }
   const bool do_bias = a.bias_out != nullptr && blockIdx.y == 0 && wk == 0;
-  f32x16 accb[2];
   half8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) accb[i][j] = 0.0f;
-
   constexpr int GQ = WG_STEP / 16, XQ = WG_STEP / 32;
   half8 gst[2][GQ], xst[2][XQ];
   auto fetch = [&](int par, int st) {
@@ -409,17 +410,18 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
     for (int q = 0; q < XQ; ++q) *(half8*)&sX[buf][lds_x + q * 32 * WG_XS] = xst[par][q];
   };
 
-  // transposing fragment read: lane = 16*g16 + u; MFMA operand lane (r = lane & 31, hh = lane >> 5) needs rows
-  // 16s + 8hh + j (j < 8) of channel r: two 4-row blocks, lane (q = u >> 2, pq = u & 3) addresses row q, cols 4pq..
-  const int g16 = lane >> 4, hh = g16 >> 1, hf = g16 & 1, u = lane & 15;
-  const int tr_row = 8 * hh + (u >> 2), tr_col = 16 * hf + 4 * (u & 3);
-  auto frag = [&](const _Float16* tile, int stride, int col0, int s) -> half8 {
-    const _Float16* q0 = tile + (tr_row + 16 * s) * stride + tr_col + col0;
+  // transposing fragment read for the 16x16x32 MFMA: operand lane (r = lane & 15, g = lane >> 4) needs 8 k values
+  // of channel r; k = 8g + j is tile row 4g + j (j < 4) / 16 + 4g + j - 4 (j >= 4) -- both operands use the same map.
+  const int g16 = lane >> 4, u = lane & 15;
+  const int tr_row = 4 * g16 + (u >> 2), tr_col = 4 * (u & 3);
+  auto frag = [&](const _Float16* tile, int stride, int col0) -> half8 {
+    const _Float16* q0 = tile + tr_row * stride + tr_col + col0;
     const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)q0);
-    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 4 * stride));
+    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 16 * stride));
     const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
     return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
   };
+  static_assert(WG_STEP == 32, "one 16x16x32 MFMA spans the rows of a step");
 
   const int n_steps = rows_per / WG_STEP, last = n_steps - 1;
   fetch(0, 0);
@@ -427,26 +429,23 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   commit(0, 0);
   __syncthreads();
   auto body = [&](auto PAR, int st) {
-    constexpr int par = decltype(PAR)::value;    // = st & 1: LDS buffer of this step; stage par is free again
+    constexpr int par = decltype(PAR)::value;
     fetch(par, st + 2 < last ? st + 2 : last);
     __builtin_amdgcn_sched_barrier(0);
+    half8 af[4], bf[4];
 #pragma unroll
-    for (int s = 0; s < WG_STEP / 16; ++s) {
-      half8 af[2], bf[2];
+    for (int i = 0; i < 4; ++i) {
+      af[i] = frag(sG[par], WG_GS, wm * 64 + 16 * i);
+      bf[i] = frag(sX[par], WG_XS, wk * 64 + 16 * i);
+    }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = frag(sG[par], WG_GS, wm * 64 + 32 * i, s);
-        bf[i] = frag(sX[par], WG_XS, wk * 64 + 32 * i, s);
-      }
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int k = 0; k < 4; ++k)
+        acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[k], acc[i][k], 0, 0, 0);
+    if (do_bias) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-          acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[k], acc[i][k], 0, 0, 0);
-      if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], ones, accb[i], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     commit(par ^ 1, par ^ 1);
@@ -459,31 +458,28 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   }
   if (st < n_steps) body(std::integral_constant<int, 0>{}, st);
 
+  // D: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int Mtot = a.m_chunks * 64, Ktot = a.k_chunks * 64;
-  const int r = lane & 31, h = lane >> 5;
-  if (do_bias && r == 0) {     // every column of accb holds the row sums; column 0 writes them
+  if (do_bias && u == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m0 = (mc0 + wm) * 64 + 32 * i;
+    for (int i = 0; i < 4; ++i) {
+      const int m0 = (mc0 + wm) * 64 + 16 * i + 4 * g16;
       if (m0 >= Mtot) continue;
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        a.bias_out[(size_t)slab * Mtot + m0 + (j & 3) + 8 * (j >> 2) + 4 * h] = accb[i][j];
+      for (int j = 0; j < 4; ++j) a.bias_out[(size_t)slab * Mtot + m0 + j] = accb[i][j];
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m0 = (mc0 + wm) * 64 + 32 * i;
+  for (int i = 0; i < 4; ++i) {
+    const int m0 = (mc0 + wm) * 64 + 16 * i + 4 * g16;
     if (m0 >= Mtot) continue;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int kk = (kc0 + wk) * 64 + 32 * k + r;
+    for (int k = 0; k < 4; ++k) {
+      const int kk = (kc0 + wk) * 64 + 16 * k + u;
       if (kk >= Ktot) continue;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int m = m0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-        a.out[((size_t)slab * Mtot + m) * Ktot + kk] = acc[i][k][j] * a.out_scale;
-      }
+      for (int j = 0; j < 4; ++j)
+        a.out[((size_t)slab * Mtot + m0 + j) * Ktot + kk] = acc[i][k][j] * a.out_scale;
     }
   }
 }
