@@ -68,3 +68,23 @@ def test_macs_c512(lib):
   assert lib.wg_create(C.byref(cfg), 0, C.byref(h)) == 0
   assert int(lib.wg_macs_per_group_step(h)) == 261355984
   lib.wg_destroy(h)
+
+
+def test_train_entry_points_validate_arguments_without_a_gpu():
+  """wg_train_* argument checks run before any device work: null members and bad geometry are reported, not crashed on."""
+  import ctypes as C
+  from waveglow_amd import _lib
+  lib = _lib.load()
+  cfg = _lib.WgConfig(80, 12, 8, 4, 2, 8, 256, 3, 1024, 256)
+  h = C.c_void_p()
+  assert lib.wg_create(C.byref(cfg), 0, C.byref(h)) == 0
+  assert lib.wg_train_workspace_bytes(h, 32, 63, 16000) > 10 * 2 ** 30          # saved activations of configs[3]
+  assert lib.wg_train_workspace_bytes(h, 32, 63, 16001) == 0                      # not a multiple of n_group
+  assert lib.wg_train_workspace_bytes(h, 32, 10, 16000) == 0                      # upsampled mel shorter than audio
+  w = _lib.WgTrainWeights()
+  dummy = (C.c_char * 64)()
+  ls = (C.c_void_p * 12)(*[C.addressof(dummy)] * 12)
+  rc = lib.wg_train_forward(h, C.byref(w), C.addressof(dummy), C.addressof(dummy), C.addressof(dummy), ls, 1, 8, 2048, 0,
+                            C.addressof(dummy), 1 << 40, None)
+  assert rc == -1 and b"null member" in lib.wg_last_error()
+  lib.wg_destroy(h)

@@ -123,6 +123,26 @@ int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* wo
   return WG_OK;
 }
 
+// every pointer of the weight / gradient blocks that the call sequence dereferences
+int check_weights(const wg_train_weights* w, int n_flows) {
+  if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->wes || !w->wat || !w->wbt || !w->wct || !w->wup || !w->bup ||
+      !w->wstart || !w->bstart || !w->out_init || !w->w1x1)
+    return wg_set_error(WG_ERR_INVALID, "wg_train_weights has a null member");
+  for (int k = 0; k < n_flows; ++k)
+    if (!w->wstart[k] || !w->bstart[k] || !w->out_init[k] || !w->w1x1[k])
+      return wg_set_error(WG_ERR_INVALID, "wg_train_weights has a null per-flow pointer");
+  return WG_OK;
+}
+int check_grads(const wg_train_grads* g, int n_flows) {
+  if (!g->dw1 || !g->db1 || !g->dw2 || !g->db2 || !g->dwes || !g->dwup || !g->dbup || !g->dstart || !g->dout_init ||
+      !g->dw1x1)
+    return wg_set_error(WG_ERR_INVALID, "wg_train_grads has a null member");
+  for (int k = 0; k < n_flows; ++k)
+    if (!g->dstart[k] || !g->dout_init[k] || !g->dw1x1[k])
+      return wg_set_error(WG_ERR_INVALID, "wg_train_grads has a null per-flow pointer");
+  return WG_OK;
+}
+
 PRun run_of(const _Float16* base, int n_chunks, int dt) {
   PRun r;
   r.base = base;
@@ -154,6 +174,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
   Ctx x;
   int rc = setup(h, B, n_frames, audio_len, workspace, workspace_bytes, x);
   if (rc) return rc;
+  if ((rc = check_weights(wt, x.c->n_flows))) return rc;
   const wg_config& c = *x.c;
   const RowGeom& g = x.g;
   TrainWs& w = x.w;
@@ -285,6 +306,7 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
   Ctx x;
   int rc = setup(h, B, n_frames, audio_len, workspace, workspace_bytes, x);
   if (rc) return rc;
+  if ((rc = check_weights(wt, x.c->n_flows)) || (rc = check_grads(gr, x.c->n_flows))) return rc;
   const wg_config& c = *x.c;
   const RowGeom& g = x.g;
   TrainWs& w = x.w;
