@@ -208,6 +208,17 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* w, const wg_train_gr
                       const float* const* g_log_s, float scale, const void* audio, int32_t B, int32_t n_frames,
                       int32_t audio_len, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward pass cut at flow boundaries: processes flows flow_hi, flow_hi-1, ..., flow_lo (0 <= flow_lo <=
+ * flow_hi < n_flows); calls must come in descending, contiguous order starting at n_flows-1, and the call with
+ * flow_lo == 0 also produces the upsample gradients.  After a call returns, the gradient slices of its flows
+ * (dw1[fl], db1[fl], dw2[fl], db2[fl], dwes[fl] for fl in [flow_lo*n_layers, (flow_hi+1)*n_layers), dstart / dout_init /
+ * dw1x1 of those flows) are final on `stream` -- a data-parallel caller can start their all-reduce while the earlier
+ * flows are still being computed (waveglow_amd/train.py). */
+int wg_train_backward_flows(wg_handle* h, const wg_train_weights* w, const wg_train_grads* grads, const float* g_z,
+                            const float* const* g_log_s, float scale, const void* audio, int32_t B, int32_t n_frames,
+                            int32_t audio_len, void* workspace, size_t workspace_bytes, int32_t flow_hi,
+                            int32_t flow_lo, void* stream);
+
 /* Diagnostic builds only (-DWG_STAMPS): device buffer of n_tiles*8 uint64 that the WN-layer kernel fills with
  * s_memtime stamps at its phase boundaries (last launch wins).  A no-op pointer in the shipped library. */
 int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer);

@@ -239,3 +239,32 @@ def test_train_step_other_widths(channels):
   loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
   assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
   _check(grads, g_ref, f"c{channels}")
+
+
+def test_backward_with_fused_per_flow_allreduce_single_rank():
+  """Data-parallel mode of the autograd node: backward cut at flow boundaries (wg_train_backward_flows) with one RCCL
+  all-reduce per flow queued behind it.  In a one-rank group the result must equal the single-call backward."""
+  import socket
+  import torch.distributed as dist
+  from waveglow_amd.train import enable_data_parallel
+  over = dict(n_channels=64, n_layers=3, n_flows=6, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 6, 2)
+  _, _, ref = _gpu_step(hp, sd, mel, wav)
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                          device_id=torch.device("cuda:0"))
+  try:
+    assert not enable_data_parallel(model)            # a single process keeps the plain path ...
+    assert enable_data_parallel(model, force=True)    # ... unless forced
+    WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
+    torch.cuda.synchronize()
+  finally:
+    dist.destroy_process_group()
+  for name, p in model.named_parameters():
+    assert torch.equal(p.grad.cpu(), ref[name]), name

@@ -66,6 +66,9 @@ SIGNATURES = {
   "wg_train_backward": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.POINTER(WgTrainGrads), C.c_void_p,
                                   C.POINTER(C.c_void_p), C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+  "wg_train_backward_flows": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.POINTER(WgTrainGrads), C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]),
   "wg_stft_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
   "wg_stft_destroy": (C.c_int, [C.c_void_p]),
   "wg_stft_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),

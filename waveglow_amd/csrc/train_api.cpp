@@ -301,6 +301,16 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
 int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_grads* gr, const float* g_z,
                       const float* const* g_log_s, float scale, const void* audio, int32_t B, int32_t n_frames,
                       int32_t audio_len, void* workspace, size_t workspace_bytes, void* stream) {
+  const wg_config* c = wg_internal_config(h);
+  if (!c) return wg_set_error(WG_ERR_INVALID, "null handle");
+  return wg_train_backward_flows(h, wt, gr, g_z, g_log_s, scale, audio, B, n_frames, audio_len, workspace, workspace_bytes,
+                                 c->n_flows - 1, 0, stream);
+}
+
+int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_train_grads* gr, const float* g_z,
+                            const float* const* g_log_s, float scale, const void* audio, int32_t B, int32_t n_frames,
+                            int32_t audio_len, void* workspace, size_t workspace_bytes, int32_t flow_hi, int32_t flow_lo,
+                            void* stream) {
   if (!wt || !gr || !audio || !workspace) return wg_set_error(WG_ERR_INVALID, "null argument");
   if (!(scale > 0.f)) return wg_set_error(WG_ERR_INVALID, "scale must be positive");
   Ctx x;
@@ -319,12 +329,17 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
   const _Float16* wat = (const _Float16*)wt->wat;
   const _Float16* wbt = (const _Float16*)wt->wbt;
 
-  // channel offsets of the peeled outputs in z (model.py:201-203, :220)
-  int z_final_ch0 = 0;
-  for (int k = 0; k < c.n_flows; ++k)
-    if (is_early(c, k)) z_final_ch0 += c.n_early_size;
+  if (flow_lo < 0 || flow_hi >= c.n_flows || flow_lo > flow_hi) return wg_set_error(WG_ERR_INVALID, "bad flow range");
+  // channel offsets of the peeled outputs in z (model.py:201-203, :220): early outputs of the flows <= k
+  auto early_channels_upto = [&](int k) {
+    int n = 0;
+    for (int q = 0; q <= k; ++q)
+      if (is_early(c, q)) n += c.n_early_size;
+    return n;
+  };
+  int z_final_ch0 = early_channels_upto(flow_hi);
 
-  for (int k = c.n_flows - 1; k >= 0; --k) {
+  for (int k = flow_hi; k >= flow_lo; --k) {
     const int ck = x.ck[k], hk = ck / 2;
     FlowBwdArgs fb;
     memset(&fb, 0, sizeof fb);
@@ -338,7 +353,7 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
     fb.g_z = g_z;
     fb.g_log_s = g_log_s ? g_log_s[k] : nullptr;
     fb.from_z = (k == c.n_flows - 1);
-    fb.z_ch0 = z_final_ch0;
+    fb.z_ch0 = early_channels_upto(c.n_flows - 1);
     fb.GZ = w.GZ;
     fb.GO = w.GO;
     TR_TRY(launch_flow_bwd_pre(fb, s));
@@ -477,6 +492,7 @@ int wg_train_backward(wg_handle* h, const wg_train_weights* wt, const wg_train_g
     TR_TRY(launch_flow_bwd_post(fb, s));
     TR_TRY(launch_slab_reduce(w.part, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], s));
   }
+  if (flow_lo > 0) return WG_OK;          // the upsample gradient needs the d pre planes of every flow
   {
     // d spect = sum over every layer of cond_layer^T d pre: ONE GEMM with K = FL*2C over the kept d pre planes
     PGemmArgs a;

@@ -225,7 +225,12 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
     logger.info("Loading states from pretrained model...")
     model.load_state_dict(warm_model.state_dict)                      # warm_start_model (train.py:85-90)
   criterion = WaveGlowLoss(sigma=hparams.sigma)
-  reducer = GradientAllReducer(model.parameters()) if world > 1 else None
+  # data parallel: gradients are averaged inside backward(), flow by flow, overlapped with the rest of the backward
+  # pass (waveglow_amd/train.py); GradientAllReducer is the unfused alternative for callers that prefer it
+  from .train import enable_data_parallel
+  reducer = None
+  if world > 1 and not enable_data_parallel(model):
+    reducer = GradientAllReducer(model.parameters())
 
   train_loader = prepare_trainloader(hparams, trainset, device)
   val_loader = prepare_valloader(hparams, valset, device)
