@@ -61,44 +61,44 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
   Cc, nl, nf, M, M8 = hp.n_channels, hp.n_layers, model.n_flows, hp.n_mel_channels, hp.n_mel_channels * 8
   dev = model.upsample.weight.device
   pm = _perms(Cc, M8, dev)
+  # Few, large autograd nodes: every per-layer slice of a big tensor costs a zero-filled full-size gradient in its
+  # backward, so layers are stacked first and split once per flow (squeeze is a view, [:, :, 0] a select).
   w_in, b_in, w_cond, b_cond, w_res, b_res, w_es, start5, out_init, w1x1 = [], [], [], [], [], [], [], [], [], []
+  pad = torch.nn.functional.pad
   for k in range(nf):
     wn = model.WN[k]
     h2 = wn.end.weight.shape[0]
-    w_end = wn.end.weight[:, :, 0]                                   # [2h, C]
-    cw = wn.cond_layer.weight[:, :, 0].view(nl, 2 * Cc, M8)
-    cb = wn.cond_layer.bias.view(nl, 2 * Cc)
-    w_skips, b_skips = [], []
-    for i in range(nl):
-      w_in.append(wn.in_layers[i].weight)                            # [2C, C, 3]
-      b_in.append(wn.in_layers[i].bias + cb[i])
-      w_cond.append(cw[i])
-      rs_w = wn.res_skip_layers[i].weight[:, :, 0]
-      rs_b = wn.res_skip_layers[i].bias
-      if i < nl - 1:                                                  # model.py:131-134
-        w_res.append(rs_w[:Cc])
-        b_res.append(rs_b[:Cc])
-        w_skips.append(rs_w[Cc:])
-        b_skips.append(rs_b[Cc:])
-      else:                                                           # model.py:135-136
-        w_res.append(torch.zeros_like(rs_w[:Cc]))
-        b_res.append(torch.zeros_like(rs_b[:Cc]))
-        w_skips.append(rs_w)
-        b_skips.append(rs_b)
-    es = torch.matmul(w_end, torch.stack(w_skips))                    # end(sum_i skip_i): [nl, 2h, C], one batched GEMM
-    w_es.append(torch.nn.functional.pad(es, (0, 0, 0, 8 - h2)))
-    out_init.append(torch.nn.functional.pad(w_end @ torch.stack(b_skips).sum(0) + wn.end.bias, (0, 8 - h2)))
-    ws = wn.start.weight[:, :, 0]                                     # [C, h]
-    s5 = torch.cat([torch.nn.functional.pad(ws, (0, 4 - ws.shape[1])).t(), wn.start.bias[None, :]], 0)   # [5, C]
+    w_end = wn.end.weight.squeeze(2)                                 # [2h, C]
+    w_cond.append(wn.cond_layer.weight.squeeze(2).view(nl, 2 * Cc, M8))
+    b_cond.append(wn.cond_layer.bias.view(nl, 2 * Cc))
+    w_in.append(torch.stack([wn.in_layers[i].weight for i in range(nl)]))            # [nl, 2C, C, 3]
+    b_in.append(torch.stack([wn.in_layers[i].bias for i in range(nl)]))
+    last_w, last_b = wn.res_skip_layers[nl - 1].weight.squeeze(2), wn.res_skip_layers[nl - 1].bias   # [C, C]: all skip
+    if nl > 1:
+      rs_w = torch.stack([wn.res_skip_layers[i].weight.squeeze(2) for i in range(nl - 1)])          # [nl-1, 2C, C]
+      rs_b = torch.stack([wn.res_skip_layers[i].bias for i in range(nl - 1)])
+      w_res.append(pad(rs_w[:, :Cc], (0, 0, 0, 0, 0, 1)))            # model.py:131-134; the last layer has no res rows
+      b_res.append(pad(rs_b[:, :Cc], (0, 0, 0, 1)))
+      w_skips = torch.cat([rs_w[:, Cc:], last_w[None]])              # model.py:135-136
+      b_skip_sum = rs_b[:, Cc:].sum(0) + last_b
+    else:
+      w_res.append(torch.zeros_like(last_w)[None])
+      b_res.append(torch.zeros_like(last_b)[None])
+      w_skips, b_skip_sum = last_w[None], last_b
+    es = torch.matmul(w_end, w_skips)                                 # end(sum_i skip_i): [nl, 2h, C], one batched GEMM
+    w_es.append(pad(es, (0, 0, 0, 8 - h2)))
+    out_init.append(pad(w_end @ b_skip_sum + wn.end.bias, (0, 8 - h2)))
+    ws = wn.start.weight.squeeze(2)                                   # [C, h]
+    s5 = torch.cat([pad(ws, (0, 4 - ws.shape[1])).t(), wn.start.bias[None, :]], 0)   # [5, C]
     start5.append(s5[:, pm.c])
-    w = model.convinv[k].conv.weight[:, :, 0]
-    w1x1.append(torch.nn.functional.pad(w, (0, 8 - w.shape[1], 0, 8 - w.shape[0])))
+    w = model.convinv[k].conv.weight.squeeze(2)
+    w1x1.append(pad(w, (0, 8 - w.shape[1], 0, 8 - w.shape[0])))
   FL = nf * nl
-  w_in = torch.stack(w_in).permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)      # K = tap-major
-  w1 = torch.cat([w_in, torch.stack(w_cond)], 2)[:, pm.c2][:, :, pm.k1]
-  b1 = torch.stack(b_in)[:, pm.c2]
-  w2 = torch.stack(w_res)[:, pm.c][:, :, pm.c]
-  b2 = torch.stack(b_res)[:, pm.c]
+  w_in = torch.cat(w_in).permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)        # K = tap-major
+  w1 = torch.cat([w_in, torch.cat(w_cond)], 2)[:, pm.c2][:, :, pm.k1]
+  b1 = (torch.cat(b_in) + torch.cat(b_cond))[:, pm.c2]
+  w2 = torch.cat(w_res)[:, pm.c][:, :, pm.c]
+  b2 = torch.cat(b_res)[:, pm.c]
   wes = torch.cat(w_es)[:, :, pm.c]                                             # [FL, 8, C]
   up = model.upsample.weight                                                    # [M_in, M_out, 1024]
   wup = up.view(M, M, 4, 32, 8).permute(3, 1, 4, 2, 0).reshape(32, M8, 4, M)    # [p][(o,g)][j][i]
