@@ -158,7 +158,7 @@ def test_training_weight_packing_reproduces_the_reference_forward():
   from waveglow_amd import synthetic
   from waveglow_amd.hparams import HParams
   from waveglow_amd.model import WaveGlow
-  from waveglow_amd.train import pack_weights, pos_perm, to_fragments
+  from waveglow_amd.train import _perms, pack_weights, pos_perm, to_fragments, to_pos_order
   hp = HParams(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
   sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=2))
   model = WaveGlow(hp)
@@ -168,8 +168,12 @@ def test_training_weight_packing_reproduces_the_reference_forward():
   S = 256 * T - 64
   wav = torch.rand(B, S, generator=torch.Generator().manual_seed(1)) * 0.6 - 0.3
   with torch.no_grad():
-    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = pack_weights(model)
     C_, nl, M8 = hp.n_channels, hp.n_layers, hp.n_mel_channels * 8
+    pm_ = _perms(C_, M8, torch.device("cpu"))
+    packed = pack_weights(model)
+    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = to_pos_order(packed, pm_)
+    back = to_pos_order(to_pos_order(packed, pm_), pm_, inverse=True)       # the gradient path's inverse gathers
+    assert all(torch.equal(a, b) for a, b in zip(packed, back))
     L = S // 8
     pc, pm = pos_perm(C_), pos_perm(M8)
     # upsample + squeeze through the per-phase matrices: spect[pos][b][t], t = 32 q + p

@@ -51,12 +51,33 @@ class _Perms:
     self.m8 = pos_perm(M8).to(device)
     self.k1 = torch.cat([pc, Cc + pc, 2 * Cc + pc, 3 * Cc + pos_perm(M8)]).to(device)
     self.r32 = pos_perm(32).to(device)
+    for name in ("c", "c2", "m8", "k1"):
+      setattr(self, "i" + name, torch.argsort(getattr(self, name)))       # inverse permutations (gradients)
     r = torch.arange(32)
     self.c2p = (16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)).to(device)   # chan_to_pos inside a 32-block
 
 
+# (tensor index in the packed tuple, dims that carry a channel-position permutation, which permutation)
+_PERM_PLAN = ((0, ((1, "c2"), (2, "k1"))), (1, ((1, "c2"),)), (2, ((1, "c"), (2, "c"))), (3, ((1, "c"),)), (4, ((2, "c"),)),
+              (5, ((1, "m8"),)), (6, ((0, "m8"),)), (7, ((2, "c"),)))
+
+
+def to_pos_order(packed, pm: "_Perms", inverse: bool = False):
+  """Natural channel order -> the kernels' position-major order (or back, for gradients).  Plain gathers, done
+  outside autograd (inside the autograd node): an indexing op under autograd costs a zero-filled full-size tensor and
+  an atomic scatter in its backward; the inverse permutation is just another gather."""
+  out = list(packed)
+  for idx, dims in _PERM_PLAN:
+    t = out[idx]
+    for dim, name in dims:
+      t = t.index_select(dim, getattr(pm, ("i" if inverse else "") + name))
+    out[idx] = t
+  return out
+
+
 def pack_weights(model) -> Tuple[torch.Tensor, ...]:
-  """Differentiable packing of the module's parameters into the (pos,pos) matrices of wg_train_weights."""
+  """Differentiable packing of the module's parameters into the stacked matrices of wg_train_weights, in NATURAL
+  channel order (to_pos_order applies the kernels' permutation)."""
   hp = model._hp
   Cc, nl, nf, M, M8 = hp.n_channels, hp.n_layers, model.n_flows, hp.n_mel_channels, hp.n_mel_channels * 8
   dev = model.upsample.weight.device
@@ -90,20 +111,23 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
     out_init.append(pad(w_end @ b_skip_sum + wn.end.bias, (0, 8 - h2)))
     ws = wn.start.weight.squeeze(2)                                   # [C, h]
     s5 = torch.cat([pad(ws, (0, 4 - ws.shape[1])).t(), wn.start.bias[None, :]], 0)   # [5, C]
-    start5.append(s5[:, pm.c])
+    start5.append(s5)
     w = model.convinv[k].conv.weight.squeeze(2)
     w1x1.append(pad(w, (0, 8 - w.shape[1], 0, 8 - w.shape[0])))
   FL = nf * nl
   w_in = torch.cat(w_in).permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)        # K = tap-major
-  w1 = torch.cat([w_in, torch.cat(w_cond)], 2)[:, pm.c2][:, :, pm.k1]
-  b1 = (torch.cat(b_in) + torch.cat(b_cond))[:, pm.c2]
-  w2 = torch.cat(w_res)[:, pm.c][:, :, pm.c]
-  b2 = torch.cat(b_res)[:, pm.c]
-  wes = torch.cat(w_es)[:, :, pm.c]                                             # [FL, 8, C]
+  w1 = torch.cat([w_in, torch.cat(w_cond)], 2)                                  # [FL, 2C, 3C + M8]
+  # "* 1.0": AddBackward hands the SAME gradient tensor to both operands and cat / stack backward only slice it, so
+  # in_layers[i].bias.grad and cond_layer.bias.grad would become overlapping views of one buffer (AccumulateGrad
+  # installs them without a copy) and the next in-place accumulation would count a gradient twice
+  b1 = torch.cat(b_in) + torch.cat(b_cond) * 1.0
+  w2 = torch.cat(w_res)
+  b2 = torch.cat(b_res)
+  wes = torch.cat(w_es)                                                         # [FL, 8, C]
   up = model.upsample.weight                                                    # [M_in, M_out, 1024]
   wup = up.view(M, M, 4, 32, 8).permute(3, 1, 4, 2, 0).reshape(32, M8, 4, M)    # [p][(o,g)][j][i]
-  wup = torch.nn.functional.pad(wup, (0, 128 - M)).reshape(32, M8, 512)[:, pm.m8]
-  bup = model.upsample.bias.repeat_interleave(8)[pm.m8]
+  wup = torch.nn.functional.pad(wup, (0, 128 - M)).reshape(32, M8, 512)
+  bup = model.upsample.bias.repeat_interleave(8)
   return (w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous(), wes.contiguous(), wup.contiguous(),
           bup.contiguous(), torch.stack(start5).contiguous(), torch.stack(out_init).contiguous(),
           torch.stack(w1x1).contiguous())
@@ -129,12 +153,12 @@ class _Weights:
   """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward)."""
 
   def __init__(self, model, packed, flow_c: List[int]):
-    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = [t.detach() for t in packed]
     hp = model._hp
     Cc, nf = hp.n_channels, model.n_flows
-    FL = w1.shape[0]
-    dev = w1.device
+    dev = packed[0].device
     pm = _perms(Cc, hp.n_mel_channels * 8, dev)
+    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = to_pos_order([t.detach() for t in packed], pm)
+    FL = w1.shape[0]
     r32, c2p = pm.r32, pm.c2p
     w1h, w2h = w1.half(), w2.half()
     self.b1, self.b2, self.bup = b1.float(), b2.float(), bup.float()
@@ -279,6 +303,7 @@ class _TrainFn(torch.autograd.Function):
         torch._foreach_mul_(grads, 1.0 / world)
     ctx.wts = None
     ctx.guard.release()
+    grads = to_pos_order(grads, _perms(model._hp.n_channels, model._hp.n_mel_channels * 8, dev), inverse=True)
     return (None, None, None, None, *grads)
 
 
