@@ -78,13 +78,16 @@ plane_gemm_kernel(const PGemmArgs a) {
   const int tpp = g.Rp / BN;
   const int tile = blockIdx.x;
   const int p = tile / tpp, r0 = (tile - p * tpp) * BN;
-  const int blk = blockIdx.y * PG_WAVES + w;
-  const bool active = blk * 32 < a.M;
+  // A residual launch can carry the folded end x skip GEMM as one extra row group (same B operand: the acts planes;
+  // 32-row matrix a.A_es, epilogue of EPI_ES) instead of a launch of its own.
+  const bool es_group = (EPI == EPI_RES) && a.A_es != nullptr && blockIdx.y == gridDim.y - 1;
+  const int blk = es_group ? w : blockIdx.y * PG_WAVES + w;
+  const bool active = blk * 32 < (es_group ? 32 : a.M);
   const size_t R64 = (size_t)g.R * 64;
 
-  const _Float16* Ap = a.A + (size_t)p * a.a_phase_stride;
+  const _Float16* Ap = (es_group ? a.A_es : a.A) + (size_t)p * a.a_phase_stride;
   const int ablk = active ? blk : 0;
-  const size_t a_step = (size_t)a.n_blk * 2048;      // elements per K-step: n_blk blocks x 4 sub-steps x 64 lanes x 8
+  const size_t a_step = (size_t)(es_group ? 1 : a.n_blk) * 2048;   // elements per K-step: blocks x 4 sub-steps x 64 lanes x 8
   const _Float16* arow[MT];
   arow[0] = Ap + (size_t)ablk * 2048 + lane * 8;
   if (MT == 2) arow[MT - 1] = Ap + (size_t)(a.M / 32 + ablk) * 2048 + lane * 8;
@@ -216,6 +219,16 @@ plane_gemm_kernel(const PGemmArgs a) {
       *(half8*)(a.o0 + addr) = T0; *(half8*)(a.o0 + addr + 8) = T1;
       *(half8*)(a.o1 + addr) = S0; *(half8*)(a.o1 + addr + 8) = S1;
       *(half8*)(a.o2 + addr) = A0; *(half8*)(a.o2 + addr + 8) = A1;
+    } else if (EPI == EPI_RES && es_group) {
+      if (blk == 0 && valid) {               // same code as EPI_ES below
+        float4* op = (float4*)(a.rows32 + ((size_t)b * g.L + t) * 8 + 4 * h);
+        float4 o = *op;
+        o.x += acc[0][ct][0] + acc[0][ct][4];
+        o.y += acc[0][ct][1] + acc[0][ct][5];
+        o.z += acc[0][ct][2] + acc[0][ct][6];
+        o.w += acc[0][ct][3] + acc[0][ct][7];
+        *op = o;
+      }
     } else if (EPI == EPI_RES) {
       half8 in0, in1, o0, o1;
       if (a.i0) { in0 = *(const half8*)(a.i0 + addr); in1 = *(const half8*)(a.i0 + addr + 8); }
@@ -270,7 +283,7 @@ plane_gemm_kernel(const PGemmArgs a) {
 namespace {
 template <int EPI>
 void launch_pg(const PGemmArgs& a, int ct, hipStream_t s) {
-  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), (a.M + 32 * PG_WAVES - 1) / (32 * PG_WAVES));
+  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), (a.M + 32 * PG_WAVES - 1) / (32 * PG_WAVES) + (EPI == EPI_RES && a.A_es ? 1 : 0));
   if (ct == 6) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 6>), grid, dim3(PG_THREADS), 0, s, a);
   else if (ct == 4) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 4>), grid, dim3(PG_THREADS), 0, s, a);
   else if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 3>), grid, dim3(PG_THREADS), 0, s, a);

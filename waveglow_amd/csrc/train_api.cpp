@@ -266,8 +266,8 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         TR_TRY(launch_plane_gemm(a, EPI_GATE, s));
       }
       if (i < nl - 1) {
-        PGemmArgs a;   // res half of res_skip_layers[i] + residual add (model.py:130-134)
-        memset(&a, 0, sizeof a);
+        PGemmArgs a;   // res half of res_skip_layers[i] + residual add (model.py:130-134), and in the same launch
+        memset(&a, 0, sizeof a);   // the skip half folded with WN.end (model.py:135-137): OUT += (W_end W_skip_i) acts
         a.n_runs = 1;
         a.run[0] = run_of(Ai, cc, 0);
         a.A = w2 + (size_t)fl * C * C;
@@ -278,10 +278,11 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.g = g;
         a.i0 = Xi;
         a.o0 = w.X + (size_t)(fl + 1) * w.plane_c;
+        a.A_es = wes + (size_t)fl * 32 * C;
+        a.rows32 = w.OUT + (size_t)k * w.rows8;
         TR_TRY(launch_plane_gemm(a, EPI_RES, s));
-      }
-      {
-        PGemmArgs a;   // skip half folded with WN.end (model.py:135-137): OUT += (W_end W_skip_i) acts
+      } else {
+        PGemmArgs a;   // last layer: no res rows, only the folded end x skip
         memset(&a, 0, sizeof a);
         a.n_runs = 1;
         a.run[0] = run_of(Ai, cc, 0);

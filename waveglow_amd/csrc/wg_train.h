@@ -48,6 +48,7 @@ struct PGemmArgs {
   _Float16 *o0, *o1, *o2;   // output planes
   const _Float16 *i0, *i1;  // epilogue input planes
   float* rows32;            // EPI_ES: OUT [B*L][8]
+  const _Float16* A_es;     // EPI_RES only, optional: 32-row end x skip matrix run as an extra row group (rows32 set)
   unsigned long long* stamps;   // diagnostics only (set by the launcher from set_plane_gemm_stamps), else null
 };
 
