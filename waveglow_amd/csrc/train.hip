@@ -381,7 +381,8 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   //           X: pieces tid + 512 q (q < WG_STEP/32): row = (tid >> 4) + 32 q, chunk e = (tid >> 3) & 1, piece = tid & 7
   const int grow = tid >> 5, ge = (tid >> 3) & 3, xrow = tid >> 4, xe = (tid >> 3) & 1, spc = tid & 7;
   const int gch = (mc0 + ge < a.m_chunks) ? mc0 + ge : a.m_chunks - 1;
-  const _Float16* gsrc = a.G + (size_t)gch * R64 + ((size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + grow) * 64 + spc * 8;
+  const _Float16* gbase = (a.G_last && gch == a.m_chunks - 1) ? a.G_last : a.G + (size_t)gch * R64;
+  const _Float16* gsrc = gbase + ((size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + grow) * 64 + spc * 8;
   const _Float16* xsrc;
   {
     int c = (kc0 + xe < a.k_chunks) ? kc0 + xe : a.k_chunks - 1;

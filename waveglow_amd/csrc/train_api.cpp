@@ -410,11 +410,15 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + (size_t)fl * n, s));
         TR_TRY(launch_slab_reduce(w.part, kPhases, 2 * C, 2 * C, inv, gr->db1 + (size_t)fl * 2 * C, s));
       }
-      if (gx) {
-        WgradArgs a;   // d W2 = d x_{i+1} x acts^T, d b2
+      {
+        // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
+        // launch with the d out plane appended to the d x planes (the last layer has no d x: d out alone)
+        WgradArgs a;
         memset(&a, 0, sizeof a);
-        a.G = gx;
-        a.m_chunks = cc;
+        const int gc = gx ? cc : 0;                 // chunks of d x
+        a.G = gx ? gx : w.GO;
+        a.G_last = gx ? w.GO : nullptr;
+        a.m_chunks = gc + 1;
         a.n_runs = 1;
         a.run[0] = run_of(Ai, cc, 0);
         a.k_chunks = cc;
@@ -424,27 +428,15 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.out_scale = 1.0f;
         a.bias_out = w.part;
         TR_TRY(launch_wgrad(a, s));
-        const size_t n = (size_t)C * C;
-        TR_TRY(launch_slab_reduce(w.slab, kPhases * small_split, n, n, inv, gr->dw2 + (size_t)fl * n, s));
-        TR_TRY(launch_slab_reduce(w.part, kPhases * small_split, C, C, inv, gr->db2 + (size_t)fl * C, s));
-      }
-      {
-        WgradArgs a;   // d (W_end W_skip_i) = d out x acts^T
-        memset(&a, 0, sizeof a);
-        a.G = w.GO;
-        a.m_chunks = 1;
-        a.n_runs = 1;
-        a.run[0] = run_of(Ai, cc, 0);
-        a.k_chunks = cc;
-        a.g = g;
-        a.row_split = small_split;
-        a.out = w.slab;
-        a.out_scale = 1.0f;
-        a.bias_out = (i == 0) ? w.part : nullptr;   // d out_init = sum over columns of (d b | d log_s), once per flow
-        TR_TRY(launch_wgrad(a, s));
-        TR_TRY(launch_slab_reduce(w.slab, kPhases * small_split, (size_t)64 * C, (size_t)8 * C, inv,
-                                  gr->dwes + (size_t)fl * 8 * C, s));
-        if (i == 0) TR_TRY(launch_slab_reduce(w.part, kPhases * small_split, 64, 8, inv, gr->dout_init[k], s));
+        const int ns = kPhases * small_split;
+        const size_t slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
+        if (gx) {
+          TR_TRY(launch_slab_reduce(w.slab, ns, slab_n, (size_t)C * C, inv, gr->dw2 + (size_t)fl * C * C, s));
+          TR_TRY(launch_slab_reduce(w.part, ns, bias_n, C, inv, gr->db2 + (size_t)fl * C, s));
+        }
+        TR_TRY(launch_slab_reduce(w.slab + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, inv, gr->dwes + (size_t)fl * 8 * C, s));
+        // d out_init = sum over columns of (d b | d log_s), once per flow
+        if (i == 0) TR_TRY(launch_slab_reduce(w.part + (size_t)gc * 64, ns, bias_n, 8, inv, gr->dout_init[k], s));
       }
       {
         PGemmArgs a;   // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)

@@ -55,8 +55,9 @@ struct PGemmArgs {
 // dW[m][k'] = sum over the rows of one slab of G[row][m] * X[row(+shift)][k']  -> out[slab][m][k'] * out_scale
 // slab = phase * row_split + part: a phase's Rp rows are cut into row_split parts (small GEMMs: more workgroups)
 struct WgradArgs {
-  const _Float16* G;        // planes [m_chunks][R][64]
-  int m_chunks;
+  const _Float16* G;        // planes [m_chunks][R][64]  (the last chunk comes from G_last when that is set)
+  const _Float16* G_last;   // optional: one more 64-channel plane appended to G (e.g. the d out plane behind d x)
+  int m_chunks;             // chunks in all, G_last included
   PRun run[kMaxRuns];       // the X operand (same runs as the forward GEMM's B operand)
   int n_runs;
   int k_chunks;             // sum n_chunks
