@@ -93,8 +93,16 @@ def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
     if T >= 256 or dt * 3.0 + spent > seconds_hint:
       break
     T = min(256, T * 2)
+  # spend the rest of a ~10 s budget on repeats of the final size and report the best of them
+  reps = 1
+  while spent + best < 0.5 * seconds_hint and reps < 8:
+    dt = run(T)
+    spent += dt
+    best = min(best, dt)
+    reps += 1
   return {"value": round(256 * T / best, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-          "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}] (configs[0] is T=500), sigma 0.6, {best:.2f} s"}
+          "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}] (configs[0] is T=500), sigma 0.6, best of {reps} runs: "
+                    f"{best:.2f} s ({spent:.1f} s of CPU work in all)"}
 
 
 def bench_train(args, rank, world, dev, dist):
