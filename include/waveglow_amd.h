@@ -96,6 +96,16 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
              int32_t n_z_early, float sigma, void* audio, int32_t B, int32_t n_frames,
              int32_t io_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* wg_infer for a batch of utterances of DIFFERENT lengths (serving; the reference's commented-out --batch-size,
+ * src/waveglow_cli/inference_v2.py:64): `frames` is a device array of B mel-frame counts, each <= n_frames; mel / noise /
+ * audio are padded to n_frames as in wg_infer (contents behind an utterance's own length are ignored, its audio tail is
+ * zero).  Every utterance gets exactly the result of a batch-of-one call on its own frames: the padding columns are never
+ * written, so they are the zero padding the convolutions see at the end of the sequence (model.py:98-102).
+ * frames == NULL is wg_infer. */
+int wg_infer_ragged(wg_handle* h, const void* mel, const int32_t* frames, const void* z_init,
+                    const void* const* z_early, int32_t n_z_early, float sigma, void* audio, int32_t B,
+                    int32_t n_frames, int32_t io_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* WaveGlow.forward (model.py:178-221), inference of the normalising direction (no autograd).
  *   mel      [B, n_mel, n_frames]     io_dtype
  *   audio    [B, audio_len]           io_dtype; audio_len % n_group == 0 and

@@ -284,3 +284,73 @@ def test_denoiser_stft_vs_numpy_oracle():
     torch.cuda.synchronize()
     assert float((out - xd).abs().max()) <= 2e-5
   lib.wg_stft_destroy(h)
+
+
+def test_ragged_batch_equals_batch_of_one_calls():
+  """wg_infer_ragged: utterances of different lengths padded into one batch give, each, bit-for-bit the audio of a
+  batch-of-one call on their own frames (same injected noise), and zeros behind their own length."""
+  hp = HParams(n_channels=64, n_layers=8, n_flows=4, n_early_every=2)
+  sd = synthetic.make_state_dict(hp, seed=6)
+  model = build_model(hp, sd)
+  lens = [37, 5, 64, 21]
+  Tm = max(lens)
+  B = len(lens)
+  mel = torch.full((B, 80, Tm), -11.5)
+  zi0, ze0 = synthetic.make_noise(hp, 1, 32)
+  z_init = torch.zeros(B, zi0.shape[1], 32 * Tm)
+  z_e = {k: torch.zeros(B, v.shape[1], 32 * Tm) for k, v in ze0.items()}
+  singles = []
+  for b, T in enumerate(lens):
+    m1 = synthetic.make_mel(1, T, seed=40 + b)
+    zi, ze = synthetic.make_noise(hp, 1, 32 * T, seed=70 + b)
+    mel[b, :, :T] = m1[0]
+    z_init[b, :, :32 * T] = zi[0]
+    for k in z_e:
+      z_e[k][b, :, :32 * T] = ze[k][0]
+    singles.append(gpu_infer(model, m1, zi, ze, 0.8))
+    # garbage behind the utterance must not matter
+    mel[b, :, T:] = 3.0
+    z_init[b, :, 32 * T:] = 7.0
+  dev = torch.device("cuda:0")
+  with torch.no_grad():
+    out = model.infer_with_noise(mel.to(dev), z_init.to(dev), [z_e[k].to(dev) for k in sorted(z_e, reverse=True)], 0.8,
+                                 frames=torch.tensor(lens, dtype=torch.int32))
+  torch.cuda.synchronize()
+  out = out.cpu()
+  for b, T in enumerate(lens):
+    assert torch.equal(out[b, :256 * T], singles[b][0]), b
+    assert float(out[b, 256 * T:].abs().max()) == 0.0 if T < Tm else True
+
+
+def test_synthesizer_batch_equals_one_by_one(tmp_path):
+  """Synthesizer.infer_batch / ``waveglow-cli synthesize --batch-size``: a ragged batch returns, per utterance, exactly
+  what ``infer`` returns for it alone with the same seed (noise drawn the same way, denoiser per utterance)."""
+  import numpy as np
+  from scipy.io import wavfile
+  from waveglow_amd import cli
+  from waveglow_amd.checkpoint import CheckpointWaveglow
+  from waveglow_amd.synthesizer import Synthesizer
+  hp = HParams(n_channels=64, n_layers=4, n_flows=4, n_early_every=2)
+  m = WaveGlow(hp)
+  m.load_state_dict(synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=8)))
+  ck_path = tmp_path / "3.pt"
+  CheckpointWaveglow.from_instances(m, None, hp, 3).save(ck_path)
+  synth = Synthesizer(CheckpointWaveglow.load(ck_path, torch.device("cuda:0")), device=torch.device("cuda:0"))
+  mels = [synthetic.make_mel(1, T, seed=20 + T) for T in (9, 30, 17)]
+  ones = [synth.infer(x, sigma=0.9, denoiser_strength=0.01, seed=11) for x in mels]
+  batch = synth.infer_batch(mels, sigma=0.9, denoiser_strength=0.01, seed=11)
+  assert len(batch) == 3
+  for a, b in zip(ones, batch):
+    assert np.array_equal(a.wav, b.wav) and np.array_equal(a.wav_denoised, b.wav_denoised)
+  # CLI: batch size 2 over 3 files == batch size 1
+  src = tmp_path / "mels"
+  src.mkdir()
+  for i, x in enumerate(mels):
+    np.save(src / f"u{i}.npy", x[0].numpy())
+  outs = []
+  for bs in ("1", "2"):
+    out = tmp_path / f"out{bs}"
+    assert cli.main(["synthesize", str(ck_path), str(src), "--custom-seed", "5", "--batch-size", bs, "-out", str(out)]) == 0
+    outs.append([wavfile.read(out / f"u{i}.wav")[1] for i in range(3)])
+  for x, y in zip(*outs):
+    assert np.array_equal(x, y)

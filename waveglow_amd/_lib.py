@@ -53,6 +53,9 @@ SIGNATURES = {
   "wg_forward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
   "wg_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_float,
                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+  "wg_infer_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32,
+                                C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                C.c_void_p]),
   "wg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                            C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -52,6 +52,8 @@ def build_parser() -> argparse.ArgumentParser:
     s.add_argument("--custom-seed", type=int, default=None)
     s.add_argument("-out", "--output-directory", type=Path, default=None)
     s.add_argument("-o", "--overwrite", action="store_true")
+    s.add_argument("--batch-size", type=int, default=1,
+                   help="utterances per launch sequence (ragged batch; results equal one-by-one synthesis)")
   for name, desc in (("train", "Start training of a new model."), ("continue-train", "Continue training from the last checkpoint.")):
     t = sub.add_parser(name, description=desc)
     t.add_argument("train_folder", type=Path, metavar="TRAIN-FOLDER")
@@ -111,17 +113,28 @@ def synthesize(ns, from_wav: bool = False) -> bool:
   if from_wav:
     from .taco_stft import TacotronSTFT
     taco_stft = TacotronSTFT(synth.hparams, device)                   # inference_wav.py:110
+  todo = []
   for mel_path in mel_files:
     wav_path = out_dir / mel_path.relative_to(ns.folder).parent / f"{mel_path.stem}.wav"
     if wav_path.exists() and not ns.overwrite:
       continue
-    if from_wav:
-      mel = taco_stft.get_mel_tensor_from_file(mel_path).unsqueeze(0)
+    todo.append((mel_path, wav_path))
+  bs = max(1, ns.batch_size)
+  for i in range(0, len(todo), bs):
+    chunk = todo[i:i + bs]
+    mels = []
+    for mel_path, _ in chunk:
+      if from_wav:
+        mels.append(taco_stft.get_mel_tensor_from_file(mel_path).unsqueeze(0))
+      else:
+        mels.append(torch.FloatTensor(np.load(mel_path)).unsqueeze(0))
+    if len(mels) == 1:
+      results = [synth.infer(mels[0], sigma=ns.sigma, denoiser_strength=ns.denoiser_strength, seed=seed)]
     else:
-      mel = torch.FloatTensor(np.load(mel_path)).unsqueeze(0)
-    res = synth.infer(mel, sigma=ns.sigma, denoiser_strength=ns.denoiser_strength, seed=seed)
-    wav_path.parent.mkdir(parents=True, exist_ok=True)
-    float_to_wav(normalize_wav(res.wav_denoised), wav_path, sample_rate=res.sampling_rate)
+      results = synth.infer_batch(mels, sigma=ns.sigma, denoiser_strength=ns.denoiser_strength, seed=seed)
+    for (_, wav_path), res in zip(chunk, results):
+      wav_path.parent.mkdir(parents=True, exist_ok=True)
+      float_to_wav(normalize_wav(res.wav_denoised), wav_path, sample_rate=res.sampling_rate)
   return True
 
 

@@ -140,6 +140,7 @@ bool is_early(const wg_config& c, int k) { return k % c.n_early_every == 0 && k 
 
 RowGeom make_geom(const wg_config& c, int B, int L, int T) {
   RowGeom g;
+  g.frames = nullptr;
   g.B = B;
   g.L = L;
   g.F = (L + kPhases - 1) / kPhases;
@@ -610,6 +611,13 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
 int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* const* z_early, int32_t n_z_early,
              float sigma, void* audio, int32_t B, int32_t n_frames, int32_t io_dtype, void* workspace,
              size_t workspace_bytes, void* stream) {
+  return wg_infer_ragged(h, mel, nullptr, z_init, z_early, n_z_early, sigma, audio, B, n_frames, io_dtype, workspace,
+                         workspace_bytes, stream);
+}
+
+int wg_infer_ragged(wg_handle* h, const void* mel, const int32_t* frames, const void* z_init, const void* const* z_early,
+                    int32_t n_z_early, float sigma, void* audio, int32_t B, int32_t n_frames, int32_t io_dtype,
+                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!h) return fail(WG_ERR_INVALID, "null handle");
   if (!h->finalized) return fail(WG_ERR_STATE, "wg_finalize has not been called");
   if (!mel || !z_init || !audio || !workspace) return fail(WG_ERR_INVALID, "null buffer");
@@ -622,6 +630,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
   const int L = n_frames * c.upsample_stride / c.n_group;
   if ((int64_t)B * L * 8 >= (1ll << 31)) return fail(WG_ERR_INVALID, "batch too large for 32-bit row indexing");
   RowGeom g = make_geom(c, B, L, n_frames);
+  g.frames = (const int*)frames;
   Workspace w = carve(h, g, (char*)workspace);
   if (w.bytes > workspace_bytes) return fail(WG_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.bytes);
   if ((size_t)g.R * 128 >= (1ull << 32)) return fail(WG_ERR_INVALID, "plane too large for 32-bit offsets");
@@ -635,6 +644,7 @@ int wg_infer(wg_handle* h, const void* mel, const void* z_init, const void* cons
   {
     MelPackArgs u;
     u.mel = mel;
+    u.frames = g.frames;
     u.melT = w.melT;
     u.B = B;
     u.M = c.n_mel_channels;
@@ -733,6 +743,7 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   {
     MelPackArgs u;
     u.mel = mel;
+    u.frames = nullptr;
     u.melT = w.melT;
     u.B = B;
     u.M = c.n_mel_channels;

@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     b = rr / Fp;
     const int fq = rr - b * Fp - a.g.Gf;
     t = fq * 32 + p;
-    return b < a.g.B && fq >= 0 && fq < a.g.F && t < a.g.L;
+    if (!(b < a.g.B && fq >= 0 && fq < a.g.F && t < a.g.L)) return false;
+    return a.g.frames == nullptr || t < 32 * a.g.frames[b];
   };
 
   // ---- tile walk.  Blocks b and b+8 share an XCD (round-robin dispatch; speed only), so XCD label x owns a
@@ -680,7 +681,7 @@ __global__ void __launch_bounds__(256) mel_pack_kernel(const MelPackArgs a) {
     float v = 0.0f;
     if (row >= 0) {
       const int b = row / rows_per_utt, f = row - b * rows_per_utt - 3;
-      if (f >= 0 && f < a.T) v = load_io(a.mel, ((size_t)b * a.M + i) * a.T + f, a.io_f16);
+      if (f >= 0 && f < (a.frames ? a.frames[b] : a.T)) v = load_io(a.mel, ((size_t)b * a.M + i) * a.T + f, a.io_f16);
     }
     a.melT[idx] = (_Float16)v;
   }
@@ -777,6 +778,9 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
     const size_t row = row0 + tid;
     if (row < nrows) {
       const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+      // ragged batch: columns behind an utterance's own length are padding -- their state is carried along (finite,
+      // never read by a valid column) but they are never written into the x / a0 planes, and their audio is zero
+      const bool pad_row = a.g.frames != nullptr && t >= 32 * a.g.frames[b];
       float zn[kMaxGroup];
 #pragma unroll
       for (int c = 0; c < kMaxGroup; ++c) zn[c] = 0.0f;
@@ -824,6 +828,10 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
           }
         }
         if (a.last) {                                                                              // :273
+          if (pad_row) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) zn[c] = 0.0f;
+          }
           if (a.io_f16) {
             half8 o;
 #pragma unroll
@@ -894,7 +902,7 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
         op[0] = make_float4(a.out_init[0], a.out_init[1], a.out_init[2], a.out_init[3]);
         op[1] = make_float4(a.out_init[4], a.out_init[5], a.out_init[6], a.out_init[7]);
         s_a0[tid] = make_float4(zn[0], zn[1], zn[2], zn[3]);
-        if (a.a0p) {   // a0 plane for the folded first WN layer: (a0_0..a0_3 | 1 | 0 0 0), see wn_layer_kernel CX = 1
+        if (a.a0p && !pad_row) {   // a0 plane for the folded first WN layer: (a0_0..a0_3 | 1 | 0 0 0), see wn_layer_kernel CX = 1
           half8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
@@ -938,6 +946,7 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
       for (int e = 0; e < 8; ++e)
         o[e] = (_Float16)fmaf(w[e][3], a0.w, fmaf(w[e][2], a0.z, fmaf(w[e][1], a0.y, fmaf(w[e][0], a0.x, bs[e]))));
       const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+      if (a.g.frames != nullptr && t >= 32 * a.g.frames[b]) continue;     // padding column of a ragged batch
       // phase-major plane row of (b, t = 32q + p), see RowGeom
       const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
       *(half8*)(a.x + ((size_t)cc * a.g.R + prow) * 64 + g8 * 8) = o;

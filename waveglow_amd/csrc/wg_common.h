@@ -48,6 +48,9 @@ struct RowGeom {
   int Rp;       // rows per phase block = B * Fp rounded up to 128
   int R;        // 32 * Rp + 2 * kRowPad  (plane rows incl. slack before row 0 and after the last row)
   int T;        // mel frames of the input (melT rows per utterance = 3 + T + 3)
+  const int* frames;   // optional (device, [B]): mel frames of every utterance of a ragged batch, each <= T; columns
+                       // t >= 32 * frames[b] of utterance b are padding: never written, so they read as the zero padding
+                       // of the convolutions exactly as in a batch-of-one call.  null: every utterance has L columns.
 };
 constexpr int kRowPad = 8;       // zero slack rows in front of / behind every plane chunk (taps of the first/last tile)
 constexpr int kPhases = 32;
@@ -79,6 +82,7 @@ struct WnLayerArgs {
 };
 
 struct MelPackArgs {
+  const int* frames;        // optional per-utterance frame counts (RowGeom::frames): frames beyond them are zero
   const void* mel;          // [B][M][T] io dtype
   _Float16* melT;           // see WnLayerArgs::melT
   int B, M, T, io_f16;

@@ -204,8 +204,10 @@ class WaveGlow(nn.Module):
 
   # ------------------------------------------------------------------ reference API
   def infer_with_noise(self, spect: torch.Tensor, z_init: torch.Tensor, z_early: List[torch.Tensor],
-                       sigma: float = 1.0) -> torch.Tensor:
-    """``infer`` with the three noise draws injected (z_early in descending flow order)."""
+                       sigma: float = 1.0, frames: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``infer`` with the three noise draws injected (z_early in descending flow order).
+    ``frames`` (int32 [B], optional): mel-frame count of every utterance of a padded batch -- each utterance then gets
+    exactly its batch-of-one result (``wg_infer_ragged``); the audio behind ``256 * frames[b]`` is zero."""
     eng = self._get_engine(spect.device)
     io = self._io_dtype(spect)
     spect = spect.contiguous()
@@ -221,8 +223,13 @@ class WaveGlow(nn.Module):
     ws = eng.workspace("infer", nbytes, (B, T, 0))
     ze = (C.c_void_p * max(1, len(z_early)))(*[z.data_ptr() for z in z_early])
     stream = torch.cuda.current_stream(spect.device).cuda_stream
-    _lib.check(eng.lib.wg_infer(eng.handle, spect.data_ptr(), z_init.data_ptr(), ze, len(z_early), float(sigma),
-                                audio.data_ptr(), B, T, io, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+    fr = None
+    if frames is not None:
+      fr = frames.to(device=spect.device, dtype=torch.int32).contiguous()
+      assert fr.shape == (B,) and int(fr.min()) >= 1 and int(fr.max()) <= T
+    _lib.check(eng.lib.wg_infer_ragged(eng.handle, spect.data_ptr(), fr.data_ptr() if fr is not None else None,
+                                       z_init.data_ptr(), ze, len(z_early), float(sigma), audio.data_ptr(), B, T, io,
+                                       ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
     return audio
 
   def infer(self, spect: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
