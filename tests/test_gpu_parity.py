@@ -354,3 +354,29 @@ def test_synthesizer_batch_equals_one_by_one(tmp_path):
     outs.append([wavfile.read(out / f"u{i}.wav")[1] for i in range(3)])
   for x, y in zip(*outs):
     assert np.array_equal(x, y)
+
+
+def test_infer_graph_replay_matches_direct_launch():
+  """hipGraph replay of wg_infer (single-utterance latency path) is bit-identical to the direct launch sequence --
+  repeatedly (the workspace is re-zeroed by a kernel inside the graph), after the inputs change, and after the weights
+  change (stale graphs are dropped together with the derived weights)."""
+  hp = HParams(n_channels=64, n_layers=8, n_flows=4, n_early_every=2)
+  sd = synthetic.make_state_dict(hp, seed=4)
+  model = build_model(hp, sd)
+  for seed in (1, 2, 3):
+    mel = synthetic.make_mel(1, 20, seed=seed).cuda()
+    z_init, z_early = synthetic.make_noise(hp, 1, 32 * 20, seed=10 + seed)
+    ze = [z_early[k].cuda() for k in sorted(z_early, reverse=True)]
+    with torch.no_grad():
+      a = model.infer_with_noise(mel, z_init.cuda(), ze, 0.7)
+      b = model.infer_with_noise(mel, z_init.cuda(), ze, 0.7, graph=True)
+      c = model.infer_with_noise(mel, z_init.cuda(), ze, 0.7, graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+  assert len(model._engine._graphs) == 1
+  with torch.no_grad():
+    model.WN[0].end.bias.add_(0.01)
+    a = model.infer_with_noise(mel, z_init.cuda(), ze, 0.7)
+    b = model.infer_with_noise(mel, z_init.cuda(), ze, 0.7, graph=True)
+  torch.cuda.synchronize()
+  assert torch.equal(a, b)

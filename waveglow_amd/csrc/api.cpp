@@ -639,7 +639,7 @@ int wg_infer_ragged(wg_handle* h, const void* mel, const int32_t* frames, const 
   {
     Prof p(h, s, 3);
     // guard rows / rows >= L of both x planes must read as zero padding (model.py:98-102)
-    HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes + w.a0_bytes, s));
+    HIP_TRY(launch_zero_fill(w.X0, 2 * w.x_bytes + w.a0_bytes, s));
   }
   {
     MelPackArgs u;
@@ -739,7 +739,7 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_channels;
   for (int k = 0; k < c.n_flows; ++k) log_det_W[k] = (float)((double)B * L * h->flows[k].logdet);   // model.py:63
-  HIP_TRY(hipMemsetAsync(w.X0, 0, 2 * w.x_bytes + w.a0_bytes, s));
+  HIP_TRY(launch_zero_fill(w.X0, 2 * w.x_bytes + w.a0_bytes, s));
   {
     MelPackArgs u;
     u.mel = mel;

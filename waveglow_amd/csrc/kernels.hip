@@ -687,6 +687,21 @@ __global__ void __launch_bounds__(256) mel_pack_kernel(const MelPackArgs a) {
   }
 }
 
+// zero fill as a KERNEL: a hipMemsetAsync issued while the stream is being captured into a hipGraph did not end up as
+// a node of the graph here (first replay right, later replays read dirty planes), a kernel launch always does
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t s) {
+  if (((size_t)p & 15) || (bytes & 15)) return hipErrorInvalidValue;
+  size_t blocks = (bytes / 16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)p, bytes / 16);
+  return hipGetLastError();
+}
+
 hipError_t launch_mel_pack(const MelPackArgs& a, hipStream_t s) {
   const size_t n = (size_t)(3 + a.B * (a.T + 6)) * a.M;
   unsigned blocks = (unsigned)((n + 255) / 256);

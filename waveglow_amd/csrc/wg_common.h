@@ -127,6 +127,7 @@ struct FlowArgs {
 
 // launch wrappers (kernels.hip)
 hipError_t launch_mel_pack(const MelPackArgs& a, hipStream_t s);
+hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t s);   // 16-byte aligned pointer and size
 // derived weights: A fragments of (W_cond slice of layer l) x (upsample taps of phase p), see api.cpp
 hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* out, int C, int NW, int M, int n_layers,
                             int up_kernel, float tanh_scale, float sigm_scale, hipStream_t s);

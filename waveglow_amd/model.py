@@ -204,10 +204,15 @@ class WaveGlow(nn.Module):
 
   # ------------------------------------------------------------------ reference API
   def infer_with_noise(self, spect: torch.Tensor, z_init: torch.Tensor, z_early: List[torch.Tensor],
-                       sigma: float = 1.0, frames: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       sigma: float = 1.0, frames: Optional[torch.Tensor] = None, graph: bool = False) -> torch.Tensor:
     """``infer`` with the three noise draws injected (z_early in descending flow order).
     ``frames`` (int32 [B], optional): mel-frame count of every utterance of a padded batch -- each utterance then gets
-    exactly its batch-of-one result (``wg_infer_ragged``); the audio behind ``256 * frames[b]`` is zero."""
+    exactly its batch-of-one result (``wg_infer_ragged``); the audio behind ``256 * frames[b]`` is zero.
+    ``graph=True`` replays the call's ~110 kernel launches from a captured hipGraph (one graph per input shape, dtype
+    and sigma; the inputs are copied into the graph's static buffers) -- for single utterances the launch gaps are a
+    measurable part of the latency.  Results are bit-identical to the direct launches."""
+    if graph:
+      return self._infer_graphed(spect, z_init, z_early, sigma, frames)
     eng = self._get_engine(spect.device)
     io = self._io_dtype(spect)
     spect = spect.contiguous()
@@ -226,11 +231,44 @@ class WaveGlow(nn.Module):
     fr = None
     if frames is not None:
       fr = frames.to(device=spect.device, dtype=torch.int32).contiguous()
-      assert fr.shape == (B,) and int(fr.min()) >= 1 and int(fr.max()) <= T
+      assert fr.shape == (B,)
+      if not torch.cuda.is_current_stream_capturing():
+        assert int(fr.min()) >= 1 and int(fr.max()) <= T
     _lib.check(eng.lib.wg_infer_ragged(eng.handle, spect.data_ptr(), fr.data_ptr() if fr is not None else None,
                                        z_init.data_ptr(), ze, len(z_early), float(sigma), audio.data_ptr(), B, T, io,
                                        ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
     return audio
+
+  def _infer_graphed(self, spect, z_init, z_early, sigma, frames):
+    eng = self._get_engine(spect.device)        # re-uploads weights if they changed: then the old graphs are stale
+    cache = eng.__dict__.setdefault("_graphs", {})
+    if eng.__dict__.get("_graphs_sig") != eng.signature:
+      cache.clear()
+      eng._graphs_sig = eng.signature
+    key = (tuple(spect.shape), spect.dtype, float(sigma), len(z_early), frames is not None)
+    ent = cache.get(key)
+    ins = [spect, z_init] + list(z_early) + ([frames.to(spect.device, torch.int32)] if frames is not None else [])
+    if ent is None:
+      st = [torch.empty_like(t) for t in ins]
+      for dst, src in zip(st, ins):
+        dst.copy_(src)
+      nz = len(z_early)
+      call = lambda: self.infer_with_noise(st[0], st[1], st[2:2 + nz], sigma, frames=st[2 + nz] if frames is not None else None)
+      side = torch.cuda.Stream(device=spect.device)
+      side.wait_stream(torch.cuda.current_stream(spect.device))
+      with torch.cuda.stream(side):             # warm-up outside capture: workspace allocation, lazy kernel loading
+        call()
+      torch.cuda.current_stream(spect.device).wait_stream(side)
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        out = call()
+      ent = (g, st, out)
+      cache[key] = ent
+    g, st, out = ent
+    for dst, src in zip(st, ins):
+      dst.copy_(src)
+    g.replay()
+    return out.clone()
 
   def infer(self, spect: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
     """model.py:223-274.  Noise is drawn with the device RNG in the tensor dtype, in the reference's
