@@ -75,6 +75,18 @@ def to_pos_order(packed, pm: "_Perms", inverse: bool = False):
   return out
 
 
+def _dense_stack(mods) -> torch.Tensor:
+  """Dense weights of same-shaped conv modules, stacked [n, out, in, k].  Weight-normed modules (the training case) are
+  evaluated with ONE ``torch._weight_norm`` over their concatenated (g, v) -- what the parametrization computes per
+  module (rows are normalised independently), in one kernel each way instead of one per module."""
+  is_p = torch.nn.utils.parametrize.is_parametrized
+  if len(mods) > 1 and all(is_p(m, "weight") for m in mods):
+    g = torch.cat([m.parametrizations.weight.original0 for m in mods])
+    v = torch.cat([m.parametrizations.weight.original1 for m in mods])
+    return torch._weight_norm(v, g, 0).view(len(mods), v.shape[0] // len(mods), *v.shape[1:])
+  return torch.stack([m.weight for m in mods])
+
+
 def pack_weights(model) -> Tuple[torch.Tensor, ...]:
   """Differentiable packing of the module's parameters into the stacked matrices of wg_train_weights, in NATURAL
   channel order (to_pos_order applies the kernels' permutation)."""
@@ -92,11 +104,11 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
     w_end = wn.end.weight.squeeze(2)                                 # [2h, C]
     w_cond.append(wn.cond_layer.weight.squeeze(2).view(nl, 2 * Cc, M8))
     b_cond.append(wn.cond_layer.bias.view(nl, 2 * Cc))
-    w_in.append(torch.stack([wn.in_layers[i].weight for i in range(nl)]))            # [nl, 2C, C, 3]
+    w_in.append(_dense_stack(list(wn.in_layers)))                                    # [nl, 2C, C, 3]
     b_in.append(torch.stack([wn.in_layers[i].bias for i in range(nl)]))
     last_w, last_b = wn.res_skip_layers[nl - 1].weight.squeeze(2), wn.res_skip_layers[nl - 1].bias   # [C, C]: all skip
     if nl > 1:
-      rs_w = torch.stack([wn.res_skip_layers[i].weight.squeeze(2) for i in range(nl - 1)])          # [nl-1, 2C, C]
+      rs_w = _dense_stack([wn.res_skip_layers[i] for i in range(nl - 1)]).squeeze(3)                # [nl-1, 2C, C]
       rs_b = torch.stack([wn.res_skip_layers[i].bias for i in range(nl - 1)])
       w_res.append(pad(rs_w[:, :Cc], (0, 0, 0, 0, 0, 1)))            # model.py:131-134; the last layer has no res rows
       b_res.append(pad(rs_b[:, :Cc], (0, 0, 0, 1)))
