@@ -286,10 +286,13 @@ def test_denoiser_stft_vs_numpy_oracle():
   lib.wg_stft_destroy(h)
 
 
-def test_ragged_batch_equals_batch_of_one_calls():
+@pytest.mark.parametrize("channels,force_bn", [(64, None), (256, "128"), (256, "64"), (512, None)])
+def test_ragged_batch_equals_batch_of_one_calls(channels, force_bn, monkeypatch):
   """wg_infer_ragged: utterances of different lengths padded into one batch give, each, bit-for-bit the audio of a
   batch-of-one call on their own frames (same injected noise), and zeros behind their own length."""
-  hp = HParams(n_channels=64, n_layers=8, n_flows=4, n_early_every=2)
+  if force_bn:
+    monkeypatch.setenv("WG_FORCE_BN", force_bn)
+  hp = HParams(n_channels=channels, n_layers=8, n_flows=4, n_early_every=2)
   sd = synthetic.make_state_dict(hp, seed=6)
   model = build_model(hp, sd)
   lens = [37, 5, 64, 21]
