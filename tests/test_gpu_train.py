@@ -268,3 +268,17 @@ def test_backward_with_fused_per_flow_allreduce_single_rank():
     dist.destroy_process_group()
   for name, p in model.named_parameters():
     assert torch.equal(p.grad.cpu(), ref[name]), name
+
+
+def test_train_step_small_mel_dimension():
+  """n_mel_channels = 32 (M8 = 256: 2 row groups of the upsample GEMM, 4 conditioning chunks), one early flow."""
+  from oracle import torch_oracle as O
+  over = dict(n_channels=64, n_layers=2, n_flows=3, n_early_every=2, n_mel_channels=32)
+  hp = HParams(**over)
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=21))
+  mel = synthetic.make_mel(3, 8, n_mel=32, seed=4)
+  wav = torch.rand(3, 256 * 8 - 40, generator=torch.Generator().manual_seed(8)) * 0.6 - 0.3
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check(grads, g_ref, "mel32")
