@@ -266,3 +266,39 @@ def test_slaney_mel_filterbank_and_mel_oracle():
   peak = int(mel[0, :, 10].argmax())
   assert abs(centres[peak] - 2000.0) < 80.0
   assert mel.min() >= np.log(1e-5) - 1e-12
+
+
+def test_nvidia_state_dict_conversion(tmp_path):
+  """converter/convert.py:37-94 on the safe route: a legacy ``weight_g / weight_v`` state_dict file becomes a checkpoint in
+  the reference's dict format (published hparams, iteration 580000) that loads into the model; a pickled module is refused."""
+  import torch
+  from waveglow_amd import synthetic
+  from waveglow_amd.checkpoint import CheckpointWaveglow
+  from waveglow_amd.converter import convert_glow, convert_glow_files
+  from waveglow_amd.hparams import HParams
+  from waveglow_amd.model import WaveGlow
+  hp = HParams(n_channels=64)                     # NVIDIA-shaped (12 flows, 8 layers) but narrow to keep the test light
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=1))
+  legacy = {}
+  for k, v in sd.items():                          # old torch.nn.utils.weight_norm names
+    k = k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v")
+    legacy[k] = v
+  src = tmp_path / "nvidia_like.pt"
+  torch.save({"model": legacy}, src)
+  ck = convert_glow(src)
+  assert ck.iteration == 580000 and ck.get_hparams().n_flows == 12 and ck.get_hparams().segment_length == 16000
+  m = WaveGlow(hp)
+  m.load_state_dict(ck.state_dict)
+  for k, v in m.state_dict().items():
+    assert torch.equal(v, sd[k]), k
+  dst = tmp_path / "580000.pt"
+  convert_glow_files(src, dst, keep_orig=False)
+  assert dst.is_file() and not src.exists()
+  assert CheckpointWaveglow.load(dst, torch.device("cpu")).iteration == 580000
+  bad = tmp_path / "module.pt"
+  torch.save({"model": torch.nn.Linear(2, 2)}, bad)   # a pickled module: refused, never executed
+  try:
+    convert_glow(bad)
+    assert False, "a pickled module must be refused"
+  except RuntimeError as ex:
+    assert "plain-tensor" in str(ex)
