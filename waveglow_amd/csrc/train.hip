@@ -25,10 +25,6 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 namespace {
 
-__device__ __forceinline__ int pos_local(int r) {   // chan_to_pos for r < 32
-  return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
-}
-
 // plane row of tile-local row rr of phase p shifted by dt group-timesteps (RowGeom)
 __device__ __forceinline__ size_t shifted_row(const RowGeom& g, int p, int dt) {
   const int pp = p + dt;
@@ -560,31 +556,6 @@ hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, si
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, n_slabs, stride, n, scale, out);
-  return hipGetLastError();
-}
-
-// per-channel sums over the rows of planes: grid (Rp/128, 32 phases, n_chunks) -> partial[(p * Rp/128 + x)][chunk*64 + ch]
-__global__ void __launch_bounds__(256) colsum_kernel(const _Float16* __restrict__ planes, int n_chunks, RowGeom g,
-                                                     float* __restrict__ partial) {
-  __shared__ float red[4][64];
-  const int ch = threadIdx.x & 63, rs = threadIdx.x >> 6;
-  const int p = blockIdx.y, chunk = blockIdx.z;
-  const _Float16* src = planes + ((size_t)chunk * g.R + kRowPad + (size_t)p * g.Rp + (size_t)blockIdx.x * 128) * 64 + ch;
-  float s = 0.0f;
-  for (int r = rs; r < 128; r += 4) s += (float)src[(size_t)r * 64];
-  red[rs][ch] = s;
-  __syncthreads();
-  if (rs == 0) {
-    const size_t slab = (size_t)p * gridDim.x + blockIdx.x;
-    partial[slab * ((size_t)n_chunks * 64) + chunk * 64 + ch] = red[0][ch] + red[1][ch] + red[2][ch] + red[3][ch];
-  }
-}
-
-int colsum_slabs(const RowGeom& g) { return kPhases * (g.Rp / 128); }
-
-hipError_t launch_colsum(const _Float16* planes, int n_chunks, const RowGeom& g, float* partial, hipStream_t s) {
-  dim3 grid(g.Rp / 128, kPhases, n_chunks);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, planes, n_chunks, g, partial);
   return hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.GZ = (float*)take(w.rows8 * 4);
   const size_t K1 = 3 * (size_t)C + M8;
   w.slab = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
-  size_t part = (size_t)max_sz((size_t)colsum_slabs(g), (size_t)kPhases * 4) * max_sz(2 * (size_t)C, (size_t)M8);
+  size_t part = (size_t)kPhases * 4 * max_sz(2 * (size_t)C, (size_t)M8);     // bias partials: [slabs][rows]
   part = max_sz(part, (size_t)flow_bwd_workgroups(g) * 64);
   part = max_sz(part, (size_t)start_wgrad_workgroups(g) * 5 * C);
   w.part = (float*)take(part * 4);

@@ -111,9 +111,6 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
                               hipStream_t s);
-// per-channel sum over all rows of fp16 planes -> partial [32 * Rp/128][n_chunks*64]
-hipError_t launch_colsum(const _Float16* planes, int n_chunks, const RowGeom& g, float* partial, hipStream_t s);
-int colsum_slabs(const RowGeom& g);
 hipError_t launch_mel_plane(const void* mel, int io_f16, int M, const RowGeom& g, _Float16* melp, hipStream_t s);
 hipError_t launch_flow_bwd_pre(const FlowBwdArgs& a, hipStream_t s);
 hipError_t launch_flow_bwd_post(const FlowBwdArgs& a, hipStream_t s);
