@@ -79,6 +79,9 @@ class _Engine:
     self.device = device
     self.signature: Optional[tuple] = None
     self._ws: Dict[Tuple[str, int, int, int], torch.Tensor] = {}
+    self._train_pool: List[dict] = []          # training workspaces (saved activations), see train_workspace
+    self._graphs: Dict[tuple, tuple] = {}      # captured hipGraphs of wg_infer, keyed by input shape / dtype / sigma
+    self._graphs_sig: Optional[tuple] = None   # weight signature the graphs were captured with
 
   def __del__(self):
     try:
@@ -113,7 +116,7 @@ class _Engine:
     ``fresh`` tells the library to clear it (guard rows must read as zero; they stay zero as long as the geometry
     ``key`` does not change).  Normally there is exactly one; a second forward() before the first backward()
     (gradient accumulation over micro-batches, two losses) gets another one instead of clobbering the first."""
-    pool = self.__dict__.setdefault("_train_pool", [])
+    pool = self._train_pool
     pool[:] = [e for e in pool if e["key"] == key and e["ws"].numel() >= nbytes]   # geometry changed: drop the old ones
     for e in pool:
       if not e["busy"]:
@@ -241,8 +244,8 @@ class WaveGlow(nn.Module):
 
   def _infer_graphed(self, spect, z_init, z_early, sigma, frames):
     eng = self._get_engine(spect.device)        # re-uploads weights if they changed: then the old graphs are stale
-    cache = eng.__dict__.setdefault("_graphs", {})
-    if eng.__dict__.get("_graphs_sig") != eng.signature:
+    cache = eng._graphs
+    if eng._graphs_sig != eng.signature:
       cache.clear()
       eng._graphs_sig = eng.signature
     key = (tuple(spect.shape), spect.dtype, float(sigma), len(z_early), frames is not None)
