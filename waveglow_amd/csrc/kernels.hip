@@ -1,16 +1,18 @@
-// gfx950 (CDNA4 / MI355X) kernels of the WaveGlow hot path.
+// gfx950 (CDNA4 / MI355X) kernels of the WaveGlow hot path (inference direction and the no-grad forward).
 //
-//   upsample_kernel   mel -> squeezed conditioning planes           (reference: src/waveglow/model.py:145-150,
-//                                                                    :225-232 / :186-193)
-//   infer_flow_kernel affine-coupling inverse + W^-1 mix + early     (model.py:247-271) fused with the NEXT
-//                     noise concat, then the next WN's start conv    flow's WN.start (model.py:117)
-//   wn_layer_kernel   one WN layer: dilated conv + cond slice as     (model.py:123-135, :13-20, :137)
-//                     ONE K-extended MFMA GEMM, gate in registers,
-//                     res GEMM + folded end*skip GEMM from LDS
+//   mel_pack_kernel   mel [B,M,T] -> frame-major fp16 rows, the B operand of the folded conditioning K-steps
+//                     (reference: src/waveglow/model.py:145-150, :225-232 / :186-193 upsample + squeeze, folded away)
+//   cond_fold_kernel  load time: cond_layer o upsample -> one [2C x 4M] matrix per layer and phase, in A-fragment order
+//   flow_kernel       affine coupling (inverse or forward) + 1x1 mix + early      (model.py:247-271 / :200-218) fused
+//                     noise concat / early output, then the next WN's start conv   with the NEXT flow's WN.start
+//                     (x_0 planes and the a0 plane of the folded first layer)      (model.py:117)
+//   wn_layer_kernel   one WN layer: dilated conv + cond slice as ONE K-extended    (model.py:123-135, :13-20, :137)
+//                     MFMA GEMM, gate in registers, res GEMM + folded end*skip GEMM from LDS
+//   reduce_sum_kernel / loss_final_kernel   WaveGlowLoss (train.py:31-45)
 //
-// Data layout (see wg_common.h): time-major fp16 planes [chunk][row][64 ch] so that every GEMM K-step's
-// B tile is BN contiguous 128-byte rows, fetched HBM/L2 -> LDS by global_load_lds (LDS-DMA), XOR-swizzled
-// through the SOURCE address (LDS destination is lane-linear).
+// Data layout (see wg_common.h): phase-major fp16 planes [chunk][row][64 ch] so that every GEMM K-step's B tile is BN
+// contiguous 128-byte rows, fetched HBM/L2 -> LDS by global_load_lds (LDS-DMA), XOR-swizzled through the SOURCE
+// address (LDS destination is lane-linear).
 #include "wg_common.h"
 
 #include <type_traits>
