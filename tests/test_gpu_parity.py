@@ -383,3 +383,33 @@ def test_infer_graph_replay_matches_direct_launch():
     b = model.infer_with_noise(mel, z_init.cuda(), ze, 0.7, graph=True)
   torch.cuda.synchronize()
   assert torch.equal(a, b)
+
+
+def test_infer_configs0_shape_against_reference_summary():
+  """BASELINE configs[0] (256 channels, mel [1,80,500] -> 128 000 samples, fp32): summary fixture written by the
+  reference's own ``WaveGlow.infer`` (tests/golden/make_golden_cfg1.py).  The noise is the reference's: its three
+  draws after ``torch.manual_seed`` are replayed here and injected."""
+  import os
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_summary.npz"))
+  hp = HParams()
+  sd = synthetic.make_state_dict(hp, seed=int(fx["weight_seed"]))    # (crc32 vs the fixture: tests/test_oracle_golden.py)
+  T, sigma = int(fx["T"]), float(fx["sigma"])
+  mel = synthetic.make_mel(1, T, seed=int(fx["mel_seed"]))
+  L = 32 * T
+  torch.manual_seed(int(fx["noise_seed"]))
+  z_init = torch.FloatTensor(1, 4, L).normal_()                   # model.py:234-244
+  z_early = {}
+  for k in reversed(range(hp.n_flows)):                           # model.py:260-271
+    if k % hp.n_early_every == 0 and k > 0:
+      z_early[k] = torch.FloatTensor(1, hp.n_early_size, L).normal_()
+  model = build_model(hp, sd)
+  out = gpu_infer(model, mel, z_init, z_early, sigma)[0]
+  assert out.numel() == int(fx["n_samples"])
+  ref = np.concatenate([fx["first"], fx["strided"], fx["last"]])
+  got = np.concatenate([out[:256].numpy(), out.numpy()[fx["strided_index"]], out[-256:].numpy()])
+  err = float(np.sqrt(np.mean((got - ref) ** 2)))
+  print(f"configs[0]: rms err on 1536 reference samples {err:.3e}; rms {float(out.pow(2).mean().sqrt()):.5f} vs {float(fx['rms']):.5f}")
+  assert err <= RMS_TOL
+  assert abs(float(out.double().pow(2).mean().sqrt()) - float(fx["rms"])) <= 1e-3
+  assert abs(float(out.double().mean()) - float(fx["mean"])) <= 1e-3
+  assert abs(float(out.abs().max()) - float(fx["max_abs"])) <= 2e-2

@@ -69,3 +69,35 @@ def test_training_gradients_match_reference():
     np.testing.assert_allclose(g.flatten()[:8].numpy(), fx["head/" + name], rtol=2e-4, atol=1e-7, err_msg=name)
     if "full/" + name in fx.files:
       np.testing.assert_allclose(g.numpy(), fx["full/" + name], rtol=2e-4, atol=1e-7, err_msg=name)
+
+
+def test_cfg1_summary_fixture_matches_oracle_and_weight_generator():
+  """tests/golden/cfg1_summary.npz (reference ``infer`` at BASELINE configs[0], T = 500): the weight generator still
+  produces the fixture's weights (crc32), and the oracle reproduces the stored samples bit-exactly on a shorter prefix
+  run is not possible (the flow is not causal), so the oracle runs the full shape once here (~10 s)."""
+  import os
+  import zlib
+  import numpy as np
+  import torch
+  from oracle import torch_oracle as O
+  from _cases import oracle_cfg_from_hp
+  from waveglow_amd import synthetic
+  from waveglow_amd.hparams import HParams
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_summary.npz"))
+  hp = HParams()
+  sd = synthetic.make_state_dict(hp, seed=int(fx["weight_seed"]))
+  crc = 0
+  for key in sorted(sd):
+    crc = zlib.crc32(sd[key].numpy().tobytes(), crc)
+  assert crc == int(fx["weights_crc32"])
+  T, sigma = int(fx["T"]), float(fx["sigma"])
+  mel = synthetic.make_mel(1, T, seed=int(fx["mel_seed"]))
+  torch.manual_seed(int(fx["noise_seed"]))
+  z_init = torch.FloatTensor(1, 4, 32 * T).normal_()
+  z_early = {}
+  for k in reversed(range(hp.n_flows)):
+    if k % hp.n_early_every == 0 and k > 0:
+      z_early[k] = torch.FloatTensor(1, hp.n_early_size, 32 * T).normal_()
+  out = O.infer_ref(sd, mel, z_init, z_early, sigma, oracle_cfg_from_hp(hp))[0]
+  assert np.array_equal(out[:256].numpy(), fx["first"]) and np.array_equal(out[-256:].numpy(), fx["last"])
+  assert np.array_equal(out.numpy()[fx["strided_index"]], fx["strided"])
