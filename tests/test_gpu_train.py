@@ -282,3 +282,30 @@ def test_train_step_small_mel_dimension():
   loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
   assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
   _check(grads, g_ref, "mel32")
+
+
+def test_train_step_configs3_shapes_against_reference_summary():
+  """BASELINE configs[3] shapes (256 channels, 16 000-sample segments, 63 mel frames; batch 2 as in the reference's CPU
+  probe): loss and the norm / sum / first 8 values of all 686 parameter gradients written by the reference's own
+  ``loss.backward()`` (tests/golden/make_golden_grads.py cfg4_b2)."""
+  fx = np.load(os.path.join(HERE, "golden", "cfg4_b2_grads.npz"))
+  hp, sd, mel, wav = _setup(dict(), 2, 63, 0, crop=256 * 63 - 16000)
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  print(f"loss gpu {loss:.6f} reference {float(fx['loss']):.6f}")
+  assert abs(loss - float(fx["loss"])) <= 2e-3 * max(1.0, abs(float(fx["loss"])))
+  worst = 0.0
+  n = 0
+  for key in fx.files:
+    if not key.startswith("norm/"):
+      continue
+    name = key[5:]
+    g = grads[name]
+    ref_norm = float(fx[key])
+    assert abs(float(g.norm()) - ref_norm) <= GRAD_TOL * ref_norm + 1e-7, name
+    head = torch.from_numpy(fx["head/" + name])
+    err = float((g.flatten()[:head.numel()] - head).norm())
+    assert err <= GRAD_TOL * max(float(head.norm()), 1e-3 * ref_norm) + 1e-7, name
+    worst = max(worst, abs(float(g.norm()) - ref_norm) / max(ref_norm, 1e-12))
+    n += 1
+  assert n == 686
+  print(f"686 gradients: worst norm deviation {worst:.2e}")
