@@ -101,3 +101,29 @@ def test_cfg1_summary_fixture_matches_oracle_and_weight_generator():
   out = O.infer_ref(sd, mel, z_init, z_early, sigma, oracle_cfg_from_hp(hp))[0]
   assert np.array_equal(out[:256].numpy(), fx["first"]) and np.array_equal(out[-256:].numpy(), fx["last"])
   assert np.array_equal(out.numpy()[fx["strided_index"]], fx["strided"])
+
+
+def test_oracle_gradients_at_configs3_shapes_match_reference_summary():
+  """oracle.grads_ref at BASELINE configs[3] shapes (256 ch, 2 x 16 000 samples) against the reference's own backward
+  (tests/golden/cfg4_b2_grads.npz: norm / sum / first 8 values per parameter)."""
+  import os
+  import numpy as np
+  import torch
+  from oracle import torch_oracle as O
+  from _cases import oracle_cfg_from_hp
+  from waveglow_amd import synthetic
+  from waveglow_amd.hparams import HParams
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_b2_grads.npz"))
+  hp = HParams()
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=0))
+  B, T, S = 2, 63, 16000
+  mel = synthetic.make_mel(B, T, seed=1234 + B + T)
+  wav = torch.rand(B, S, generator=torch.Generator().manual_seed(99 + T)) * 0.6 - 0.3
+  loss, grads = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(float(loss) - float(fx["loss"])) <= 1e-6
+  for key in fx.files:
+    if key.startswith("norm/"):
+      name = key[5:]
+      g = grads[name]
+      assert abs(float(g.norm()) - float(fx[key])) <= 1e-5 * float(fx[key]) + 1e-9, name
+      assert np.allclose(g.flatten()[:8].numpy(), fx["head/" + name], rtol=1e-4, atol=1e-8), name
