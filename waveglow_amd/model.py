@@ -292,7 +292,8 @@ class WaveGlow(nn.Module):
     spect, audio = forward_input
     if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
       from .train import train_forward
-      return train_forward(self, spect, audio)
+      # grad_scale: loss scale of the fp16 gradient planes (0 = automatic, 2^round(log2 N) for the reference's mean loss)
+      return train_forward(self, spect, audio, float(getattr(self, "grad_scale", 0.0)))
     eng = self._get_engine(spect.device)
     io = self._io_dtype(spect)
     assert audio.dtype == spect.dtype and audio.device == spect.device

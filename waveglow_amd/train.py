@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Tuple
 
 import torch
@@ -315,6 +316,9 @@ class _TrainFn(torch.autograd.Function):
         torch._foreach_mul_(grads, 1.0 / world)
     ctx.wts = None
     ctx.guard.release()
+    if os.environ.get("WG_TRAIN_CHECK_FINITE") == "1" and not bool(torch.isfinite(dstart).all()):
+      raise _lib.WgError("non-finite gradients: the fp16 gradient planes overflowed (or the inputs held inf / nan); lower "
+                         "model.grad_scale (currently %g)" % ctx.scale)
     grads = to_pos_order(grads, _perms(model._hp.n_channels, model._hp.n_mel_channels * 8, dev), inverse=True)
     return (None, None, None, None, *grads)
 
