@@ -309,3 +309,24 @@ def test_train_step_configs3_shapes_against_reference_summary():
     n += 1
   assert n == 686
   print(f"686 gradients: worst norm deviation {worst:.2e}")
+
+
+def test_custom_grad_scale_and_finite_check(monkeypatch):
+  """model.grad_scale only moves the fp16 gradient planes' exponent: results agree with the automatic scale; an absurd
+  scale overflows the planes and WG_TRAIN_CHECK_FINITE=1 reports it instead of handing nan gradients to the optimiser."""
+  from waveglow_amd._lib import WgError
+  over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 6, 2)
+  _, _, ref = _gpu_step(hp, sd, mel, wav)
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  model.grad_scale = 256.0
+  WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
+  for name, p in model.named_parameters():
+    assert float((p.grad.cpu() - ref[name]).norm()) <= 5e-3 * float(ref[name].norm()) + 1e-8, name
+  monkeypatch.setenv("WG_TRAIN_CHECK_FINITE", "1")
+  model.zero_grad()
+  model.grad_scale = 1e30
+  with pytest.raises(WgError):
+    WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
