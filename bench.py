@@ -42,6 +42,26 @@ def wn_layer_macs_per_group_step(hp) -> float:
   return total
 
 
+def wn_layer_executed_macs_per_group_step(hp) -> float:
+  """MACs the wn_layer launches actually EXECUTE per group-timestep, after the algebraic folds of DESIGN.md section 2
+  (cond_layer o upsample: K 640 -> 320; WN.end folded into the skip rows: the skip half of res_skip and `end` become
+  16 rows; in_layers[0] o start: 3 K-steps of 64 instead of 3C/64 in the first layer of every WN)."""
+  C_, M = hp.n_channels, hp.n_mel_channels
+  per_flow = 0.0
+  for i in range(hp.n_layers):
+    k1 = (3 * 64 if i == 0 else 3 * C_) + 4 * M
+    per_flow += 2 * C_ * k1 + (C_ * C_ if i < hp.n_layers - 1 else 0) + 16 * C_
+  return per_flow * hp.n_flows
+
+
+def workload_label(args) -> str:
+  """Which BASELINE.json config the arguments are (index into its `configs` list), or "custom"."""
+  key = (args.channels, args.batch, args.frames, args.dtype)
+  named = {(256, 1, 500, "fp32"): "configs[0]", (256, 16, 864, "fp16"): "configs[1]", (512, 64, 864, "fp16"): "configs[2]",
+           (256, 32, 4000, "fp16"): "configs[4] (one GPU's shard of 32)"}
+  return named.get(key, "custom")
+
+
 def pmc_traffic_bytes(args):
   """HBM bytes per wn_layer launch from the committed PMC passes (profiles/pmc_traffic.json), or None when the
   bench shape differs from the profiled one.  bench.py cannot collect PMC counters itself."""
@@ -255,6 +275,8 @@ def main():
     launches_per_step = hp.n_flows * hp.n_layers
     flops_per_launch = 2.0 * wn_layer_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
     achieved = flops_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
+    executed_per_launch = 2.0 * wn_layer_executed_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
+    executed = executed_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
     out = {
       "metric": "audio samples/sec/GPU (22.05 kHz) WaveGlow-256 infer; real-time factor",
       "value": round(value, 1),
@@ -268,7 +290,8 @@ def main():
       "vs_baseline": None,
       "dtype": "f16 MFMA operands, f32 accumulate/flow state, %s I/O" % args.dtype,
       "data": "synthetic (random 80xT log-mels, synthetic weights of the LJS-v3 256ch architecture)",
-      "config": {"workload": f"configs[1]: {args.channels}ch WaveGlow.infer, batch={B}/GPU mels 80x{T}, sigma=0.6",
+      "config": {"workload": f"{workload_label(args)}: {args.channels}ch WaveGlow.infer, batch={B}/GPU mels 80x{T}, "
+                             f"{args.dtype} I/O, sigma=0.6",
                  "per_gpu_samples_per_step": B * T * 256, "parallelism": f"utterance-sharded x{world}, no collective"},
       "real_time_factor": round(value / 22050.0, 1),
       "samples_per_s_per_gpu": round(value / world, 1),
@@ -276,6 +299,9 @@ def main():
                    "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4),
                    "traffic": pmc_traffic_bytes(args), "avg_launch_ms": round(avg_wn_ms, 4), "launches_timed": n_wn,
                    "algorithmic_flops_per_launch": flops_per_launch,
+                   # what the matrix cores actually execute after the weight folds (fewer MACs for the same result)
+                   "executed_flops_per_launch": executed_per_launch, "executed_achieved": round(executed, 2),
+                   "executed_frac": round(executed / PEAK_FP16_DENSE_TFLOPS, 4),
                    "kernel_ms_per_step": {"mel_pack": round(ms[0] / args.steps, 3), "flow_start": round(ms[1] / args.steps, 3),
                                           "wn_layer": round(ms[2] / args.steps, 3), "memset": round(ms[3] / args.steps, 3)}},
     }

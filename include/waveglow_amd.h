@@ -199,6 +199,13 @@ typedef struct wg_train_grads {
   float* const* dout_init;   /* [8] */
   float* const* dw1x1;       /* [8][8], top-left [c_k][c_k] used: the W.z term only; the logdet term (model.py:63) is
                                 the caller's */
+  /* Record layout of dw1 / db1 / dw2 / db2 / dwes (elements of float).  Both 0: every tensor is dense, entry fl at
+   * fl * (its own size).  Otherwise entry fl = flow*n_layers + layer of each of the five lies at
+   * base + flow*flow_stride + layer*layer_stride: a data-parallel caller interleaves the five tensors of a layer in one
+   * record and the records of a flow (plus its dstart / dout_init / dw1x1) in one contiguous region, so that a flow's
+   * gradients travel as ONE all-reduce message (waveglow_amd/train.py: GradBuffers). */
+  int64_t layer_stride;
+  int64_t flow_stride;
 } wg_train_grads;
 
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len);

@@ -20,7 +20,7 @@ from waveglow_amd.model import WaveGlow, WaveGlowLoss
 
 pytestmark = pytest.mark.gpu
 
-GRAD_TOL = 2e-2
+GRAD_TOL = 5e-3     # measured worst case 1.1e-3
 FWD_TOL = 2e-3
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -325,8 +325,12 @@ def test_custom_grad_scale_and_finite_check(monkeypatch):
   WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
   for name, p in model.named_parameters():
     assert float((p.grad.cpu() - ref[name]).norm()) <= 5e-3 * float(ref[name].norm()) + 1e-8, name
-  monkeypatch.setenv("WG_TRAIN_CHECK_FINITE", "1")
+  assert bool(model.grad_finite)                    # device-side flag over ALL gradient tensors, read by train()
   model.zero_grad()
   model.grad_scale = 1e30
+  WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
+  assert not bool(model.grad_finite)
+  monkeypatch.setenv("WG_TRAIN_CHECK_FINITE", "1")
+  model.zero_grad()
   with pytest.raises(WgError):
     WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()

@@ -302,3 +302,39 @@ def test_nvidia_state_dict_conversion(tmp_path):
     assert False, "a pickled module must be refused"
   except RuntimeError as ex:
     assert "plain-tensor" in str(ex)
+
+
+def test_wav_helpers_match_reference_fixture(tmp_path):
+  """normalize_wav / convert_wav / float_to_wav / is_overamp against outputs of the reference's own audio_utils.py
+  (tests/golden/make_golden_audio.py): bit-exact, incl. the bytes of the written wav file and the inputs the reference
+  rejects with an AssertionError."""
+  import os
+  import numpy as np
+  import pytest
+  from waveglow_amd import audio as A
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "audio_utils.npz"))
+  names = sorted({k.split("/")[0] for k in fx.files})
+  assert len(names) == 9
+  n_assert = 0
+  for name in names:
+    x = fx[f"{name}/in"]
+    assert bool(A.is_overamp(x)) == bool(fx[f"{name}/is_overamp"]), name
+    if bool(fx[f"{name}/normalize_asserts"]):
+      n_assert += 1
+      with pytest.raises(AssertionError):
+        A.normalize_wav(x.copy())
+      normalized = None
+    else:
+      normalized = A.normalize_wav(x.copy())
+      ref = fx[f"{name}/normalized"]
+      assert normalized.dtype == ref.dtype and np.array_equal(normalized, ref), name
+    if x.dtype in (np.float32, np.float64):
+      got = A.convert_wav(x.copy(), np.int16)
+      assert got.dtype == np.int16 and np.array_equal(got, fx[f"{name}/as_int16"]), name
+      p = tmp_path / f"{name}.wav"
+      A.float_to_wav(normalized if normalized is not None else x, p)
+      assert np.array_equal(np.frombuffer(p.read_bytes(), dtype=np.uint8), fx[f"{name}/wav_bytes"]), name
+    else:
+      got = A.convert_wav(x.copy(), np.float32)
+      assert got.dtype == np.float32 and np.array_equal(got, fx[f"{name}/as_float32"]), name
+  assert n_assert >= 1

@@ -127,3 +127,55 @@ def test_oracle_gradients_at_configs3_shapes_match_reference_summary():
       g = grads[name]
       assert abs(float(g.norm()) - float(fx[key])) <= 1e-5 * float(fx[key]) + 1e-9, name
       assert np.allclose(g.flatten()[:8].numpy(), fx["head/" + name], rtol=1e-4, atol=1e-8), name
+
+
+def test_big_summary_fixtures_weight_generator_and_c256_weightnorm_fold():
+  """tests/golden/make_golden_big.py fixtures: the weight generator still produces the weights the reference ran with
+  (crc32) for cfg3 (512 ch, T = 864) and cfg5 (256 ch, T = 4000) -- their audio is checked on the GPU only (the oracle
+  needs ~1-2 minutes for each) -- and for c256_wn the oracle on the folded weights g*v/||v|| (model.py:276-297)
+  reproduces the reference's audio bit-exactly."""
+  import ast
+  import os
+  import zlib
+  import numpy as np
+  import torch
+  from oracle import torch_oracle as O
+  from _cases import oracle_cfg_from_hp
+  from waveglow_amd import synthetic
+  from waveglow_amd.hparams import HParams
+  gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+  def crc_of(sd):
+    crc = 0
+    for key in sorted(sd):
+      crc = zlib.crc32(sd[key].numpy().tobytes(), crc)
+    return crc
+  for name in ("cfg3_summary.npz", "cfg5_summary.npz"):
+    fx = np.load(os.path.join(gold, name))
+    hp = HParams(**dict(ast.literal_eval(str(fx["hp_json"]))))
+    assert crc_of(synthetic.make_state_dict(hp, seed=int(fx["weight_seed"]))) == int(fx["weights_crc32"]), name
+    assert int(fx["n_samples"]) == 256 * int(fx["T"]) and fx["strided"].shape == fx["strided_index"].shape
+  fx = np.load(os.path.join(gold, "c256_wn.npz"))
+  hp = HParams()
+  sd = synthetic.make_state_dict(hp, seed=int(fx["weight_seed"]))
+  assert crc_of(sd) == int(fx["weights_crc32"])
+  wn = synthetic.to_weightnorm_form(sd)
+  gen = torch.Generator().manual_seed(int(fx["g_seed"]))
+  dense = {}
+  for key in sorted(wn):
+    if key.endswith("original0"):
+      g = wn[key] * (0.5 + torch.rand(wn[key].shape, generator=gen))
+      v = wn[key.replace("original0", "original1")]
+      dense[key.replace("parametrizations.weight.original0", "weight")] = torch._weight_norm(v, g, 0)
+    elif not key.endswith("original1"):
+      dense[key] = wn[key]
+  T = int(fx["T"])
+  mel = synthetic.make_mel(1, T, seed=int(fx["mel_seed"]))
+  torch.manual_seed(int(fx["noise_seed"]))
+  z_init = torch.FloatTensor(1, 4, 32 * T).normal_()
+  z_early = {}
+  for k in reversed(range(hp.n_flows)):
+    if k % hp.n_early_every == 0 and k > 0:
+      z_early[k] = torch.FloatTensor(1, hp.n_early_size, 32 * T).normal_()
+  out = O.infer_ref(dense, mel, z_init, z_early, float(fx["sigma"]), oracle_cfg_from_hp(hp))
+  assert np.array_equal(out.numpy(), fx["audio"])

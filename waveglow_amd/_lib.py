@@ -30,7 +30,8 @@ class WgTrainWeights(C.Structure):
 class WgTrainGrads(C.Structure):
   """wg_train_grads: device pointers; the last three are arrays of n_flows pointers."""
   _fields_ = [(n, C.c_void_p) for n in (
-    "dw1", "db1", "dw2", "db2", "dwes", "dwup", "dbup", "dstart", "dout_init", "dw1x1")]
+    "dw1", "db1", "dw2", "db2", "dwes", "dwup", "dbup", "dstart", "dout_init", "dw1x1")] + [
+    ("layer_stride", C.c_int64), ("flow_stride", C.c_int64)]
 
 
 class WgError(RuntimeError):
@@ -101,6 +102,14 @@ def load() -> C.CDLL:
     fn.argtypes = args
   _lib = lib
   return lib
+
+
+def device_index(device) -> int:
+  """Ordinal of a 'cuda' torch.device; an index-less ``torch.device('cuda')`` means torch's CURRENT device (under
+  LOCAL_RANK > 0 that is not GPU 0)."""
+  import torch
+  device = torch.device(device)
+  return device.index if device.index is not None else torch.cuda.current_device()
 
 
 def check(rc: int) -> None:

@@ -32,6 +32,10 @@ def normalize_wav(wav: np.ndarray) -> np.ndarray:
     if orig in (np.int16, np.int32):
       wf = np.round(wf, 0)
     wav = wf.astype(orig)
+  # the reference checks its own result (audio_utils.py:92-93) -- which makes it REJECT inputs whose float32 round trip
+  # does not land exactly on the maximum (float64 signals, large int32): same behaviour here
+  assert np.max(np.abs(wav)) == hi or np.max(np.abs(wav)) == 0
+  assert not is_overamp(wav)
   return wav
 
 

@@ -507,6 +507,12 @@ int wg_finalize(wg_handle* h) {
       for (int r = 0; r < 8; ++r) oi[r] = (float)out_bias[r];
     }
   }
+  // the library works on h->device without changing the caller's current device for good
+  struct DeviceGuard {
+    int prev = -1;
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } dev_guard;
+  HIP_TRY(hipGetDevice(&dev_guard.prev));
   HIP_TRY(hipSetDevice(h->device));
   {
     int ncu = 0;
@@ -733,9 +739,11 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   if ((int64_t)(n_frames - 1) * c.upsample_stride + c.upsample_kernel < audio_len)
     return fail(WG_ERR_INVALID, "upsampled mel (%d frames) shorter than audio (%d)", n_frames, audio_len);
   const int L = audio_len / c.n_group;
+  if ((int64_t)B * L * 8 >= (1ll << 31)) return fail(WG_ERR_INVALID, "batch too large for 32-bit row indexing");
   RowGeom g = make_geom(c, B, L, n_frames);
   Workspace w = carve(h, g, (char*)workspace);
   if (w.bytes > workspace_bytes) return fail(WG_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.bytes);
+  if ((size_t)g.R * 128 >= (1ull << 32)) return fail(WG_ERR_INVALID, "plane too large for 32-bit offsets");
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_channels;
   for (int k = 0; k < c.n_flows; ++k) log_det_W[k] = (float)((double)B * L * h->flows[k].logdet);   // model.py:63

@@ -63,6 +63,11 @@ int wg_stft_create(const float* fwd_basis, const float* inv_basis, const float* 
         }
   wg_stft* h = new wg_stft();
   h->device = device_id;
+  struct DeviceGuard {   // restore the caller's current device on every exit path
+    int prev = -1;
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } dev_guard;
+  HIP_TRY2(hipGetDevice(&dev_guard.prev));
   HIP_TRY2(hipSetDevice(device_id));
   HIP_TRY2(hipMalloc((void**)&h->d_fwdA, fa.size() * 4));
   HIP_TRY2(hipMalloc((void**)&h->d_invA, ia.size() * 4));

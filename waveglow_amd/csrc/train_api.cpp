@@ -329,6 +329,13 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   const int small_split = 4;                           // Rp is a multiple of 128 = 4 parts of whole 32-row steps
   const _Float16* wat = (const _Float16*)wt->wat;
   const _Float16* wbt = (const _Float16*)wt->wbt;
+  // where entry fl of a per-layer gradient tensor lives: dense, or in interleaved per-layer records (wg_train_grads)
+  if ((gr->layer_stride == 0) != (gr->flow_stride == 0) || gr->layer_stride < 0 || gr->flow_stride < 0)
+    return wg_set_error(WG_ERR_INVALID, "wg_train_grads: layer_stride and flow_stride must both be 0 or both positive");
+  auto gofs = [&](int fl, size_t dense) -> size_t {
+    return gr->layer_stride ? (size_t)(fl / nl) * (size_t)gr->flow_stride + (size_t)(fl % nl) * (size_t)gr->layer_stride
+                            : (size_t)fl * dense;
+  };
 
   if (flow_lo < 0 || flow_hi >= c.n_flows || flow_lo > flow_hi) return wg_set_error(WG_ERR_INVALID, "bad flow range");
   // channel offsets of the peeled outputs in z (model.py:201-203, :220): early outputs of the flows <= k
@@ -407,8 +414,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.bias_out = w.part;
         TR_TRY(launch_wgrad(a, s));
         const size_t n = (size_t)2 * C * K1;
-        TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + (size_t)fl * n, s));
-        TR_TRY(launch_slab_reduce(w.part, kPhases, 2 * C, 2 * C, inv, gr->db1 + (size_t)fl * 2 * C, s));
+        TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + gofs(fl, n), s));
+        TR_TRY(launch_slab_reduce(w.part, kPhases, 2 * C, 2 * C, inv, gr->db1 + gofs(fl, (size_t)2 * C), s));
       }
       {
         // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
@@ -431,10 +438,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         const int ns = kPhases * small_split;
         const size_t slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
         if (gx) {
-          TR_TRY(launch_slab_reduce(w.slab, ns, slab_n, (size_t)C * C, inv, gr->dw2 + (size_t)fl * C * C, s));
-          TR_TRY(launch_slab_reduce(w.part, ns, bias_n, C, inv, gr->db2 + (size_t)fl * C, s));
+          TR_TRY(launch_slab_reduce(w.slab, ns, slab_n, (size_t)C * C, inv, gr->dw2 + gofs(fl, (size_t)C * C), s));
+          TR_TRY(launch_slab_reduce(w.part, ns, bias_n, C, inv, gr->db2 + gofs(fl, (size_t)C), s));
         }
-        TR_TRY(launch_slab_reduce(w.slab + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, inv, gr->dwes + (size_t)fl * 8 * C, s));
+        TR_TRY(launch_slab_reduce(w.slab + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, inv, gr->dwes + gofs(fl, (size_t)8 * C), s));
         // d out_init = sum over columns of (d b | d log_s), once per flow
         if (i == 0) TR_TRY(launch_slab_reduce(w.part + (size_t)gc * 64, ns, bias_n, 8, inv, gr->dout_init[k], s));
       }

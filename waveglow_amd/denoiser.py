@@ -46,7 +46,7 @@ class Denoiser(torch.nn.Module):
     fwd, inv, wsq = stft_bases(hparams.filter_length, hparams.hop_length, hparams.win_length)
     self._h = C.c_void_p()
     _lib.check(self.lib.wg_stft_create(fwd.ctypes.data, inv.ctypes.data, wsq.ctypes.data, hparams.filter_length,
-                                       hparams.hop_length, device.index or 0, C.byref(self._h)))
+                                       hparams.hop_length, _lib.device_index(device), C.byref(self._h)))
     w = waveglow.upsample.weight
     if mode == "zeros":
       mel = torch.zeros((1, hparams.n_mel_channels, BIAS_MEL_LENGTH), dtype=w.dtype, device=w.device)

@@ -73,7 +73,7 @@ class _Engine:
     cfg = _lib.WgConfig(hp.n_mel_channels, hp.n_flows, hp.n_group, hp.n_early_every, hp.n_early_size,
                         hp.n_layers, hp.n_channels, hp.kernel_size, 1024, 256)
     handle = C.c_void_p()
-    _lib.check(lib.wg_create(C.byref(cfg), device.index if device.index is not None else 0, C.byref(handle)))
+    _lib.check(lib.wg_create(C.byref(cfg), _lib.device_index(device), C.byref(handle)))
     self.lib = lib
     self.handle = handle
     self.device = device
@@ -102,6 +102,9 @@ class _Engine:
     _lib.check(self.lib.wg_finalize(self.handle))
 
   def workspace(self, kind: str, nbytes: int, key: Tuple[int, int, int]) -> torch.Tensor:
+    """One cached workspace (the last shape's).  A captured hipGraph bakes its workspace's device pointer in, so
+    ``_infer_graphed`` keeps its own reference in the graph's cache entry: evicting here never frees memory that a
+    graph will still write to."""
     k = (kind,) + key
     ws = self._ws.get(k)
     if ws is None or ws.numel() < nbytes:
@@ -184,6 +187,8 @@ class WaveGlow(nn.Module):
     if device.type != "cuda":
       raise _lib.WgError("waveglow_amd runs on MI355X only: move the model and inputs to a 'cuda' (ROCm) device; "
                          "there is no CPU fallback")
+    if device.index is None:
+      device = torch.device("cuda", torch.cuda.current_device())
     if self._engine is None or self._engine.device != device:
       self._engine = _Engine(self._hp, device)
     if not need_weights:     # training direction: weights are handed over per call (waveglow_amd/train.py)
@@ -262,12 +267,16 @@ class WaveGlow(nn.Module):
       with torch.cuda.stream(side):             # warm-up outside capture: workspace allocation, lazy kernel loading
         call()
       torch.cuda.current_stream(spect.device).wait_stream(side)
+      B_, _, T_ = spect.shape
+      ws = eng._ws.get(("infer", B_, T_, 0))    # allocated by the warm-up; the graph's kernels write to THIS memory
+      assert ws is not None
       g = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g):
         out = call()
-      ent = (g, st, out)
+      assert eng._ws.get(("infer", B_, T_, 0)) is ws
+      ent = (g, st, out, ws)                    # ws: kept alive as long as the graph (see _Engine.workspace)
       cache[key] = ent
-    g, st, out = ent
+    g, st, out, _ws = ent
     for dst, src in zip(st, ins):
       dst.copy_(src)
     g.replay()

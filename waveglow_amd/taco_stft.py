@@ -88,7 +88,7 @@ class TacotronSTFT(torch.nn.Module):
     fwd, inv, wsq = stft_bases(hparams.filter_length, hparams.hop_length, hparams.win_length, hparams.window)
     self._h = C.c_void_p()
     _lib.check(self.lib.wg_stft_create(fwd.ctypes.data, inv.ctypes.data, wsq.ctypes.data, hparams.filter_length,
-                                       hparams.hop_length, device.index or 0, C.byref(self._h)))
+                                       hparams.hop_length, _lib.device_index(device), C.byref(self._h)))
     basis = slaney_mel_filterbank(hparams.sampling_rate, hparams.filter_length, hparams.n_mel_channels,
                                   hparams.mel_fmin, hparams.mel_fmax)
     self.register_buffer("mel_basis", torch.from_numpy(basis).to(device))

@@ -239,6 +239,92 @@ def enable_data_parallel(model, group=None, force: bool = False) -> bool:
   return True
 
 
+class GradBuffers:
+  """All gradients of one backward pass in ONE flat fp32 buffer, laid out so that everything that becomes final
+  with flow k's backward is contiguous (few, large messages -- xGMI rings are per-link bound):
+
+    [ flow 0 region | flow 1 region | ... | tail ]
+    flow region = n_layers records (dw1 | db1 | dw2 | db2 | dwes of one layer) | dstart [5,C] | dout_init [8] | dw1x1 [8,8]
+    tail        = dwup [32, M8, 512] | dbup [M8]
+
+  The library writes through strided views (wg_train_grads.layer_stride / flow_stride); ``regions[k]`` is what a
+  data-parallel run all-reduces right behind flow k's backward, ``tail`` goes last.  12 + 1 messages per step at the
+  reference's 12 flows (25.3 MB per flow, 5.2 MB tail at 256 channels)."""
+
+  def __init__(self, Cc: int, nl: int, nf: int, M8: int, device):
+    K1 = 3 * Cc + M8
+    sizes = (2 * Cc * K1, 2 * Cc, Cc * Cc, Cc, 8 * Cc)
+    self.rec = sum(sizes)
+    small = (5 * Cc, 8, 64)
+    self.flow_stride = nl * self.rec + sum(small)
+    n_tail = 32 * M8 * 512 + M8
+    self.flat = torch.zeros(nf * self.flow_stride + n_tail, dtype=torch.float32, device=device)
+    self.regions = [self.flat[k * self.flow_stride:(k + 1) * self.flow_stride] for k in range(nf)]
+    self.tail = self.flat[nf * self.flow_stride:]
+    st = lambda shape, strides, off: self.flat.as_strided(shape, strides, off)
+    off, fs, rec = 0, self.flow_stride, self.rec
+    self.dw1 = st((nf, nl, 2 * Cc, K1), (fs, rec, K1, 1), off); off += sizes[0]
+    self.db1 = st((nf, nl, 2 * Cc), (fs, rec, 1), off); off += sizes[1]
+    self.dw2 = st((nf, nl, Cc, Cc), (fs, rec, Cc, 1), off); off += sizes[2]
+    self.db2 = st((nf, nl, Cc), (fs, rec, 1), off); off += sizes[3]
+    self.dwes = st((nf, nl, 8, Cc), (fs, rec, Cc, 1), off)
+    off = nl * rec
+    self.dstart = st((nf, 5, Cc), (fs, Cc, 1), off); off += small[0]
+    self.dout_init = st((nf, 8), (fs, 1), off); off += small[1]
+    self.dw1x1 = st((nf, 8, 8), (fs, 8, 1), off)
+    self.dwup = self.tail[:32 * M8 * 512].view(32, M8, 512)
+    self.dbup = self.tail[32 * M8 * 512:]
+    self.nf = nf
+
+  def struct(self):
+    """(wg_train_grads, keep-alive list)."""
+    arr = lambda t: (C.c_void_p * self.nf)(*[t[k].data_ptr() for k in range(self.nf)])
+    keep = [arr(self.dstart), arr(self.dout_init), arr(self.dw1x1)]
+    g = _lib.WgTrainGrads(_ptr(self.dw1), _ptr(self.db1), _ptr(self.dw2), _ptr(self.db2), _ptr(self.dwes),
+                          _ptr(self.dwup), _ptr(self.dbup), C.cast(keep[0], C.c_void_p), C.cast(keep[1], C.c_void_p),
+                          C.cast(keep[2], C.c_void_p), self.rec, self.flow_stride)
+    return g, keep
+
+  def packed_grads(self, pm: "_Perms") -> list:
+    """Gradients in the shapes / natural channel order of pack_weights' outputs (the inverse channel permutation is a
+    gather per tensor, which also makes the strided per-layer views dense)."""
+    nf = self.nf
+    sel = lambda t, dim, name: t.index_select(dim, getattr(pm, "i" + name))
+    dw1 = sel(sel(self.dw1, 2, "c2"), 3, "k1")
+    db1 = sel(self.db1, 2, "c2")
+    dw2 = sel(sel(self.dw2, 2, "c"), 3, "c")
+    db2 = sel(self.db2, 2, "c")
+    dwes = sel(self.dwes, 3, "c")
+    merge = lambda t: t.reshape(t.shape[0] * t.shape[1], *t.shape[2:])
+    return [merge(dw1), merge(db1), merge(dw2), merge(db2), merge(dwes), sel(self.dwup, 1, "m8"), sel(self.dbup, 0, "m8"),
+            sel(self.dstart, 2, "c"), self.dout_init.contiguous(), self.dw1x1.contiguous()]
+
+
+def flow_backward_schedule(n_flows: int, run_flow, bufs, group=None) -> None:
+  """The data-parallel backward schedule, independent of what computes the gradients (so that the CPU tests drive it
+  with a stub): flows are processed last to first; as soon as ``run_flow(k)`` has queued flow k's backward its region of
+  the flat gradient buffer is final on the stream and goes out as ONE asynchronous all-reduce (RCCL runs on its own
+  stream, ordered after the work queued so far), overlapping the backward of flows k-1 .. 0; the tail (upsample
+  gradients, final with flow 0) follows; then everything is awaited and divided by the world size -- the reference's
+  loss is a mean over the LOCAL batch (train.py:44), so the mean over ranks is the gradient of the concatenated batch.
+  ``bufs`` needs ``regions`` (one tensor per flow), ``tail`` and ``flat``.  ``group`` None: no exchange."""
+  if group is None:
+    for k in reversed(range(n_flows)):
+      run_flow(k)
+    return
+  import torch.distributed as dist
+  works = []
+  for k in reversed(range(n_flows)):
+    run_flow(k)
+    works.append(dist.all_reduce(bufs.regions[k], op=dist.ReduceOp.SUM, group=group, async_op=True))
+  works.append(dist.all_reduce(bufs.tail, op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for wk in works:
+    wk.wait()
+  world = dist.get_world_size(group)
+  if world > 1:
+    bufs.flat.mul_(1.0 / world)
+
+
 class _TrainFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, model, mel, audio, scale, *packed):
@@ -276,12 +362,10 @@ class _TrainFn(torch.autograd.Function):
     B, F_, S = ctx.dims
     dev = ctx.audio.device
     nf = model.n_flows
-    grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
-    dw1, db1, dw2, db2, dwes, dwup, dbup, dstart, dout_init, dw1x1 = grads
-    arr = lambda t: (C.c_void_p * nf)(*[t[k].data_ptr() for k in range(nf)])
-    a_start, a_init, a_1x1 = arr(dstart), arr(dout_init), arr(dw1x1)
-    gstruct = _lib.WgTrainGrads(_ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dwes), _ptr(dwup), _ptr(dbup),
-                                C.cast(a_start, C.c_void_p), C.cast(a_init, C.c_void_p), C.cast(a_1x1, C.c_void_p))
+    hp = model._hp
+    pm = _perms(hp.n_channels, hp.n_mel_channels * 8, dev)
+    bufs = GradBuffers(hp.n_channels, hp.n_layers, nf, hp.n_mel_channels * 8, dev)
+    gstruct, _keep = bufs.struct()
     gz = g_z.float().contiguous() if g_z is not None else None
     gls = [g.float().contiguous() if g is not None else None for g in g_log_s]
     gl_arr = (C.c_void_p * nf)(*[(g.data_ptr() if g is not None else None) for g in gls])
@@ -293,34 +377,32 @@ class _TrainFn(torch.autograd.Function):
                                        C.c_float(ctx.scale), _ptr(ctx.audio), B, F_, S, _ptr(ctx.ws), ctx.ws.numel(),
                                        C.c_void_p(stream)))
     else:
-      # Data parallel: the gradients of a flow are final as soon as that flow's backward has run, so their
-      # all-reduce (one ~25 MB message per flow: dw1 | dw2 | dwes | biases of its layers) is launched right behind it
-      # and overlaps the backward of the earlier flows (RCCL runs on its own stream, ordered after the work queued
-      # so far).  The packing ops that follow in autograd are linear in these gradients, so averaging here equals
-      # averaging the parameter gradients (the logdet term of the 1x1 weights is identical on every rank).
-      import torch.distributed as dist
-      world = dist.get_world_size(group)
-      nl = model._hp.n_layers
-      works = []
-      for k in reversed(range(nf)):
+      # Data parallel: the backward pass is cut at flow boundaries and every flow's gradients -- ONE contiguous region
+      # of the flat buffer -- are all-reduced right behind it (flow_backward_schedule).  The packing ops that follow in
+      # autograd are linear in these gradients, so averaging here equals averaging the parameter gradients (the logdet
+      # term of the 1x1 weights is identical on every rank).
+      def run_flow(k):
         _lib.check(lib.wg_train_backward_flows(eng.handle, C.byref(wts.struct), C.byref(gstruct), gz_ptr, gl_arr,
                                                C.c_float(ctx.scale), _ptr(ctx.audio), B, F_, S, _ptr(ctx.ws),
                                                ctx.ws.numel(), k, k, C.c_void_p(stream)))
-        for t in (dw1, db1, dw2, db2, dwes):
-          works.append(dist.all_reduce(t[k * nl:(k + 1) * nl], op=dist.ReduceOp.SUM, group=group, async_op=True))
-      for t in (dwup, dbup, dstart, dout_init, dw1x1):
-        works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
-      for wk in works:
-        wk.wait()
-      if world > 1:
-        torch._foreach_mul_(grads, 1.0 / world)
+      flow_backward_schedule(nf, run_flow, bufs, group)
     ctx.wts = None
     ctx.guard.release()
-    if os.environ.get("WG_TRAIN_CHECK_FINITE") == "1" and not bool(torch.isfinite(dstart).all()):
-      raise _lib.WgError("non-finite gradients: the fp16 gradient planes overflowed (or the inputs held inf / nan); lower "
-                         "model.grad_scale (currently %g)" % ctx.scale)
-    grads = to_pos_order(grads, _perms(model._hp.n_channels, model._hp.n_mel_channels * 8, dev), inverse=True)
+    # Overflow of the fp16 gradient planes (the automatic scale 2^round(log2 N) assumes the reference's MEAN loss; a
+    # loss with another normalisation needs model.grad_scale) or inf / nan inputs: every gradient tensor is checked,
+    # on the device.  model.grad_finite is read by waveglow_amd.training.train() before the optimiser step;
+    # WG_TRAIN_CHECK_FINITE=1 raises here (one host sync per step).
+    model.grad_finite = torch.isfinite(bufs.flat).all()
+    if os.environ.get("WG_TRAIN_CHECK_FINITE") == "1" and not bool(model.grad_finite):
+      raise _lib.WgError(nonfinite_message(ctx.scale))
+    grads = bufs.packed_grads(pm)
     return (None, None, None, None, *grads)
+
+
+def nonfinite_message(scale: float) -> str:
+  return ("non-finite gradients: the fp16 gradient planes overflowed (or the inputs held inf / nan).  The automatic loss "
+          "scale assumes the reference's mean-normalised WaveGlowLoss (train.py:43-44); for a differently normalised loss "
+          "set model.grad_scale (currently %s) so that scale * |dL/dz| stays below 65504" % (("%g" % scale) if scale else "automatic"))
 
 
 def train_forward(model, mel: torch.Tensor, audio: torch.Tensor, grad_scale: float = 0.0):

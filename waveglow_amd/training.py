@@ -24,7 +24,7 @@ from .checkpoint import CheckpointWaveglow
 from .distributed import GradientAllReducer
 from .hparams import HParams, overwrite_custom_hparams
 from .model import WaveGlow, WaveGlowLoss
-from .sharding import shard_list
+from .sharding import equal_shard_list
 from .taco_stft import TacotronSTFT
 
 PYTORCH_EXT = ".pt"
@@ -216,7 +216,9 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
   rank = torch.distributed.get_rank() if dist_on else 0
   world = torch.distributed.get_world_size() if dist_on else 1
   if world > 1:
-    trainset = shard_list(list(trainset), rank, world)
+    # equal shards: every rank takes the same number of steps per epoch (the all-reduces inside backward() pair up
+    # step by step); up to world-1 files at the end of the list sit out
+    trainset = equal_shard_list(list(trainset), rank, world)
 
   model = load_model(hparams, checkpoint.state_dict if checkpoint is not None else None, device)
   optimizer = load_optimizer(model.parameters(), hparams, checkpoint.optimizer if checkpoint is not None else None)
@@ -238,6 +240,12 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
   if batch_iterations == 0:
     logger.error("Not enough training data.")
     raise Exception()
+  if world > 1:
+    n = torch.tensor([batch_iterations, -batch_iterations], dtype=torch.int64,
+                     device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+    torch.distributed.all_reduce(n, op=torch.distributed.ReduceOp.MAX)
+    if int(n[0]) != batch_iterations or int(-n[1]) != batch_iterations:
+      raise Exception(f"rank {rank}: {batch_iterations} steps per epoch, other ranks between {int(-n[1])} and {int(n[0])}")
 
   model.train()
   train_start = time.perf_counter()
@@ -260,6 +268,10 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
       loss.backward()
       if reducer is not None:
         reducer.reduce()
+      finite = getattr(model, "grad_finite", None)      # set by the library's backward (waveglow_amd/train.py)
+      if finite is not None and not bool(finite):
+        from .train import nonfinite_message
+        raise Exception(nonfinite_message(float(getattr(model, "grad_scale", 0.0))))
       optimizer.step()
       iteration += 1
       losses.append(reduced_loss)
