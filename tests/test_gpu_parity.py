@@ -171,7 +171,7 @@ def test_forward_golden(name):
 # Round-trip bounds.  fp32 I/O: the only error is the kernels' own (fp16 MFMA operands).  fp16 I/O: the audio handed from
 # infer to forward is ROUNDED to fp16 (relative 2^-11 of O(1) samples), an input perturbation of the forward pass that no
 # kernel can undo; the bound is that perturbation's measured effect with margin, not a kernel tolerance.
-ROUND_TRIP_TOL = {torch.float32: 3e-3, torch.float16: 1.5e-2}
+ROUND_TRIP_TOL = {torch.float32: 1e-3, torch.float16: 1.5e-3}    # measured 2.6e-4 / 3.9e-4
 
 
 def _round_trip(model, B, T, sigma, dtype, seed=7):
