@@ -87,6 +87,11 @@ constexpr bool kXTileDMA = kPersistent;
 // wait lies a long stretch of compiler-scheduled code, and hipcc moved the still-in-flight destination registers
 // there -- wrong results.  They are loaded at the tile top: ~1 L2 latency exposed per tile.)
 constexpr int kTilesPerWG = 2;        // tiles per workgroup (template TPW), fully unrolled; 1 for small workloads
+#ifdef WG_NO_PIPE_EPI
+constexpr bool kPipeEpi = false;      // A/B builds: the round-1 epilogue (gate, barrier, GEMM 2, end x skip, stores in sequence)
+#else
+constexpr bool kPipeEpi = true;       // gate of column chunk c overlapped with GEMM 2 of chunk c-1 (see "pipelined epilogue")
+#endif
 // Tried and measured slower on MI355X, kept out of the source: staging B tiles global -> VGPR -> ds_write instead
 // of LDS-DMA (K loop 59.3k vs 57.6k cycles per tile); offsetting the VMEM slots of the two waves of a SIMD
 // (two copies of the loop made hipcc spill).
@@ -221,10 +226,23 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     asm volatile("" : "=v"(dst));
 #endif
   };
-  // column -> (utterance, frame): rr = row inside the phase block
+  // column -> (utterance, frame): rr = row inside the phase block, one of the BN consecutive rows of the current tile.
+  // The utterance of the tile's first row (tile_b0, wave-uniform: one scalar division per tile) is at most one
+  // utterance behind every other row's when Fp >= BN, so the per-lane integer division (~25 VALU instructions incl. a
+  // transcendental, in phases that are VALU-bound) reduces to a compare and a subtract.
+  int tile_b0 = 0;
+  const bool fp_ge_bn = Fp >= BN;
   auto column_of = [&](int rr, int p, int& b, int& t) -> bool {
-    b = rr / Fp;
-    const int fq = rr - b * Fp - a.g.Gf;
+    int rem = rr - tile_b0 * Fp;
+    b = tile_b0;
+    if (fp_ge_bn) {
+      if (rem >= Fp) { rem -= Fp; ++b; }
+    } else {
+      const int qd = rem / Fp;
+      b += qd;
+      rem -= qd * Fp;
+    }
+    const int fq = rem - a.g.Gf;
     t = fq * 32 + p;
     if (!(b < a.g.B && fq >= 0 && fq < a.g.F && t < a.g.L)) return false;
     return a.g.frames == nullptr || t < 32 * a.g.frames[b];
@@ -250,6 +268,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   // bias of GEMM1 (pre-scaled: in_layer bias + cond_layer bias slice + W_cond . upsample bias), fp32 [2C], in LDS
   float* const sBias = (float*)(sActs + BN * ACT_ROW);
   for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
+  if constexpr (HAS_RES)
+    for (int i = tid; i < C; i += NTHREADS) sBias[2 * C + i] = a.bias2[i];   // b_res, read by the pipelined epilogue
 
   half8 q[4][MT];
   int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
@@ -267,6 +287,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int p = tile / a.tiles_per_phase;           // phase of every column of this tile
     const int jt = tile - p * a.tiles_per_phase;
     const int rr0 = jt * BN;                          // first row inside the phase block
+    tile_b0 = rr0 / Fp;
     const int r0 = kRowPad + p * Rp + rr0;            // first plane row of this tile
     const int next_tile = tile + tile_step;
     wA1c_p = (const char*)a.wA1c + (size_t)p * (2 * a.n_cond_steps) * NW * (NAH * 1024);
@@ -434,13 +455,204 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     asm volatile("" : "+v"(lno), "+v"(lho), "+v"(laneo));
     char* const acts_lane = sActs + lno * ACT_ROW + lho * 32;      // this lane's write slot in row n = lno
     const char* const acts_rd = sActs + lno * ACT_ROW + lho * 16;  // B-fragment read base (k16 = 0)
-    // ---- issue the loads the post-gate phases need now, so their latency hides under the gate's VALU work:
-    // residual input x (this tile, this wave's channels: lane (n, h) owns positions [32*blk + 16h, +16) of
-    // column n = 32 contiguous bytes) and the first GEMM2 weight fragments.
+    // ---- folded end x skip (model.py:133-137): out[0:8] += (W_end W_skip_i) acts, 16 columns per group, weights split
+    // hi+lo fp16 (rows 0-7 / 8-15 of the 16x16x32 MFMA) so the 8 flow outputs keep ~fp32 weights.  Two parts: the
+    // loads (weight fragments, the out rows to update) are issued early, the MFMAs run once every acts row is in LDS.
+    const int l15 = laneo & 15, l4 = laneo >> 4;
+    constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
+    constexpr bool kWesEarly = (C / 32) * 4 <= 32;           // folded-end weight fragments fit beside GEMM2's registers
+    half8 wes[C / 32];
+    float4 es_o[NGRP];
+    float4* es_op[NGRP];
+    bool es_valid[NGRP];
+    auto es_prefetch = [&]() {
+      const half8* pe = (const half8*)a.wEs + laneo;
+#pragma unroll
+      for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
+#pragma unroll
+      for (int gi = 0; gi < NGRP; ++gi) {
+        const int grp = wave + gi * NW;
+        es_valid[gi] = false;
+        es_o[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        es_op[gi] = nullptr;
+        if (grp < BN / 16) {
+          int cb, ct;
+          es_valid[gi] = column_of(rr0 + grp * 16 + l15, p, cb, ct) && laneo < 32;
+          es_op[gi] = (float4*)(a.out + ((size_t)cb * a.g.L + ct) * 8 + 4 * l4);
+          if (es_valid[gi]) es_o[gi] = *es_op[gi];
+        }
+      }
+    };
+    auto es_compute = [&]() {
+#pragma unroll
+      for (int gi = 0; gi < NGRP; ++gi) {
+        const int grp = wave + gi * NW;
+        if (grp < BN / 16) {
+          const char* ep = sActs + (grp * 16 + l15) * ACT_ROW + l4 * 16;
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < C / 32; ++s) {
+            const half8 bfe = *(const half8*)(ep + s * 64);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wes[s], bfe, d, 0, 0, 0);
+          }
+          // D: col = lane&15, row = 4*(lane>>4)+reg ; rows 8-15 (lanes 32-63) are the lo parts
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[r] += __shfl_xor(d[r], 32);
+          if (es_valid[gi]) {
+            float4 o = es_o[gi];
+            o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
+            *es_op[gi] = o;
+          }
+        }
+      }
+    };
+    constexpr bool PIPE = kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
+    auto read_acts32 = [&](int nt, int k16) -> half8 {       // B fragment for the 32x32x16 MFMA
+      return *(const half8*)(acts_rd + nt * 32 * ACT_ROW + k16 * 32);
+    };
     constexpr int PF = 8 / MB;                // GEMM2 A-fragment prefetch depth (per 32-channel block)
     half8 xres[MB][NT][2];
     half8 a2[MB][PF];
     const half8* const p2 = (const half8*)a.wA2 + (size_t)wave * MB * K2 * 64 + laneo;
+    f32x16 acc2[MB][NT];
+    if constexpr (PIPE) {
+      // ---- pipelined epilogue.  The gate is VALU-bound (2 exp2 + 1 rcp per element at quarter rate) and GEMM 2 is
+      // MFMA-bound; run back to back they leave the matrix pipe idle for the whole gate and the VALU idle for the
+      // whole GEMM 2.  Here the tile's NT column chunks (32 columns = one N tile each) go through a software pipeline:
+      //     phase c :   gate(chunk c) -> acts rows of chunk c in LDS      ||      GEMM 2 (chunk c-1) -> x_out rows of c-1
+      // with ONE barrier between phases (GEMM 2 of a chunk contracts over the channels of all waves).  Inside a phase
+      // the two instruction streams are interleaved by hand, one MFMA (+ its LDS fragment read, two slots ahead) and
+      // one gate element per slot; the gate itself is software-pipelined over three slots (A: clamp + 2 exp2,
+      // B: denominator + rcp, C: numerator, product, fp16 pack) so that no slot waits on a transcendental.
+      // The wave's GEMM-2 weight fragments (K2 x 1 KiB) stay in registers for all chunks: the accumulators of the
+      // chunks already gated are dead by then, and a chunk's acc2 is only 16 registers.
+      constexpr int SL = 16;                                  // slots per phase = gate elements per lane and chunk
+      const int blk = wave;                                   // MB == 1
+      half8 a2r[K2];                                          // loaded in the slots of phase 0 (first use: phase 1)
+      const float* const sBias2 = sBias + 2 * C;              // b_res, fp32 [C], staged next to the GEMM-1 bias
+      // Residual add (model.py:131-132) on the matrix pipe: x_out = b_res + P x + W_res acts, where P selects this
+      // wave's 32 channels of x -- two more k16 steps whose A fragments are a constant 0/1 matrix (row r = natural
+      // channel r of the block, k = storage position chan_to_pos(r)) and whose B fragments are the x rows themselves,
+      // loaded straight in B-fragment order.  x (fp16) times 1.0 accumulated in fp32 is exact, and it replaces 32 VALU
+      // instructions per chunk (16 cvt + 16 add) in phases that are VALU-bound while the matrix pipe has room.
+      half8 idA[2];
+      {
+        const int pr = 16 * ((lno >> 2) & 1) + 4 * (lno >> 3) + (lno & 3);     // chan_to_pos of row r = lno inside a 32-block
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) idA[sx][j] = (_Float16)((16 * sx + 8 * lho + j) == pr ? 1.0f : 0.0f);
+      }
+      half8 xr[2];                                            // residual x of the chunk whose GEMM 2 runs next (B fragments)
+      auto load_xr = [&](int nt) {
+        const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
+        const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lho * 8);
+        xr[0] = xp[0];                                        // positions 8h .. 8h+7       (k16 step 0)
+        xr[1] = xp[2];                                        // positions 16 + 8h .. +7    (k16 step 1)
+      };
+      load_xr(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c <= NT; ++c) {
+        const bool do_gate = c < NT, do_mm = c >= 1;
+        f32x16 d2;                                            // GEMM 2 accumulator of chunk c-1: x + b_res + W_res acts
+        if (do_mm) {
+          const float4* bp = (const float4*)(sBias2 + blk * 32 + 4 * lho);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = bp[2 * g];
+            d2[4 * g + 0] = b4.x;
+            d2[4 * g + 1] = b4.y;
+            d2[4 * g + 2] = b4.z;
+            d2[4 * g + 3] = b4.w;
+          }
+          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[0], xr[0], d2, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[1], xr[1], d2, 0, 0, 0);
+        }
+        if (do_mm && c < NT) load_xr(c);                      // residual of chunk c: phase c+1 starts from it
+        if (c == NT - 1) es_prefetch();                       // end x skip weights + out rows: consumed in the last phase
+        if (c == NT) es_compute();                            // every acts row is in LDS (barrier of phase NT-1)
+        // gate pipeline state (static indices after unrolling)
+        float e1[SL], den[SL], rc[SL];
+        half8 o0, o1;
+        auto stageA = [&](int e) {
+          const int nt = c < NT ? c : 0;
+          const float u = __builtin_amdgcn_fmed3f(acc[0][nt][e], -60.0f, 60.0f);
+          e1[e] = __builtin_amdgcn_exp2f(u);
+          den[e] = __builtin_amdgcn_exp2f(acc[MB][nt][e]);
+        };
+        auto stageB = [&](int e) {
+          const float t = 1.0f + den[e];
+          rc[e] = __builtin_amdgcn_rcpf(fmaf(e1[e], t, t));
+        };
+        auto stageC = [&](int e) {
+          // (E1 - 1) * rc as ONE fma (exactly rounded once); kept scalar: v_pk_*_f32 costs more per element than a
+          // plain VALU instruction here (tools/ubench/valu_costs.hip)
+          float v = fmaf(e1[e], rc[e], -rc[e]);
+          asm volatile("" : "+v"(v));
+          if (e < 8) o0[e] = (_Float16)v; else o1[e - 8] = (_Float16)v;
+        };
+        // K2 <= SL (MB == 1: C <= 256): slot i carries the MFMA of k16 step k when k = i*K2/SL changes at i+1
+        static_assert(K2 <= SL, "one GEMM-2 MFMA per slot at most");
+        half8 bq[K2];
+        const int ntm = c >= 1 ? c - 1 : 0;
+        auto k_of = [](int i) { return i * K2 / SL; };
+        auto has_k = [&](int i) { return i >= 0 && i < SL && k_of(i) != k_of(i + 1); };
+        if (do_gate) { stageA(0); stageA(1); stageB(0); }
+        if (do_mm) {
+          if (has_k(0)) bq[k_of(0)] = read_acts32(ntm, k_of(0));
+          if (has_k(1)) bq[k_of(1)] = read_acts32(ntm, k_of(1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SL; ++i) {
+          if (do_mm) {
+            if (has_k(i + 2)) bq[k_of(i + 2)] = read_acts32(ntm, k_of(i + 2));   // fragment read two slots ahead
+            if (has_k(i)) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2r[k_of(i)], bq[k_of(i)], d2, 0, 0, 0);
+          }
+          if (c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
+          if (do_gate) {
+            if (i + 2 < SL) stageA(i + 2);
+            if (i + 1 < SL) stageB(i + 1);
+            if (i & 1) { stageC(i - 1); stageC(i); }
+            if (i == 7) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64) = o0;          // positions [32 blk + 16 h, +8)
+            if (i == SL - 1) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64 + 16) = o1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_mm) {
+          // x_out rows of chunk c-1 = fp16(x + b_res + W_res acts) for valid columns (model.py:130-132); every other row
+          // of the plane stays zero: it is the convolution padding of other tiles
+          int cb, ct;
+          if (column_of(rr0 + ntm * 32 + lno, p, cb, ct)) {
+            half8 q0, q1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              q0[r] = (_Float16)d2[r];
+              q1[r] = (_Float16)d2[8 + r];
+            }
+            const size_t row = (size_t)(blk >> 1) * R + r0 + ntm * 32 + lno;
+            half8* xp = (half8*)(a.x_out + row * 64 + (blk & 1) * 32 + lho * 16);
+            xp[0] = q0;
+            xp[1] = q1;
+          }
+        }
+        if (do_gate) {
+          // acts of chunk c complete in LDS for every wave before anyone's GEMM 2 reads them.  Raw barrier: the x_out
+          // stores and the next tile's LDS-DMA stay in flight across it (a __syncthreads() fence would drain them).
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (c == 0) WG_STAMP(3);
+        }
+      }
+      WG_STAMP(4);
+    }
+    if constexpr (!PIPE) {
+    // ---- issue the loads the post-gate phases need now, so their latency hides under the gate's VALU work:
+    // residual input x (this tile, this wave's channels: lane (n, h) owns positions [32*blk + 16h, +16) of
+    // column n = 32 contiguous bytes) and the first GEMM2 weight fragments.
     if constexpr (HAS_RES) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
@@ -479,7 +691,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     WG_STAMP(3);
 
     // GEMM2 accumulators start from x + b_res (residual add for free, model.py:132)
-    f32x16 acc2[MB][NT];
     if constexpr (HAS_RES) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
@@ -497,24 +708,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     }
 
-    auto read_acts32 = [&](int nt, int k16) -> half8 {       // B fragment for the 32x32x16 MFMA
-      return *(const half8*)(acts_rd + nt * 32 * ACT_ROW + k16 * 32);
-    };
+    }   // !PIPE
 
-    // ---- folded end x skip, part 1: issue the weight-fragment loads now, consume after GEMM2
-    const int l15 = laneo & 15, l4 = laneo >> 4;
-    constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
-    constexpr bool kWesEarly = (C / 32) * 4 <= 32;           // folded-end weight fragments fit beside GEMM2's registers
-    half8 wes[C / 32];
-    auto load_wes = [&]() {
-      const half8* pe = (const half8*)a.wEs + laneo;
-#pragma unroll
-      for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
-    };
-    if constexpr (kWesEarly) load_wes();                     // issue now, consume after GEMM2
+
+    if constexpr (kWesEarly && !PIPE) es_prefetch();          // issue now, consume after GEMM2
 
     // ---- GEMM2: res rows of this wave (model.py:130-132); acts fragments read one k16 step ahead
-    if constexpr (HAS_RES) {
+    if constexpr (HAS_RES && !PIPE) {
       half8 bq[2][NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bq[0][nt] = read_acts32(nt, 0);
@@ -535,40 +735,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     }
 
-    WG_STAMP(4);
-    if constexpr (!kWesEarly) load_wes();
-    // ---- folded end x skip (model.py:133-137): out[0:8] += (W_end W_skip_i) acts, 16 columns per group,
-    // weights split hi+lo fp16 (rows 0-7 / 8-15 of the 16x16x32 MFMA) so the 8 flow outputs keep ~fp32 weights.
-#pragma unroll
-    for (int gi = 0; gi < NGRP; ++gi) {
-      const int grp = wave + gi * NW;
-      if (grp < BN / 16) {
-        const int n = grp * 16 + l15;
-        int cb, ct;
-        const bool valid = column_of(rr0 + n, p, cb, ct) && laneo < 32;
-        float4* op = (float4*)(a.out + ((size_t)cb * a.g.L + ct) * 8 + 4 * l4);
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) o = *op;
-        const char* ep = sActs + n * ACT_ROW + l4 * 16;
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < C / 32; ++s) {
-          const half8 bfe = *(const half8*)(ep + s * 64);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wes[s], bfe, d, 0, 0, 0);
-        }
-        // D: col = lane&15, row = 4*(lane>>4)+reg ; rows 8-15 (lanes 32-63) are the lo parts
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] += __shfl_xor(d[r], 32);
-        if (valid) {
-          o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
-          *op = o;
-        }
-      }
+    if constexpr (!PIPE) {
+      WG_STAMP(4);
+      if constexpr (!kWesEarly) es_prefetch();
+      es_compute();
     }
 
     WG_STAMP(5);
     // ---- x_out = fp16(x + res) for valid columns (all other rows stay zero: they are the padding of other tiles)
-    if constexpr (HAS_RES) {
+    if constexpr (HAS_RES && !PIPE) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         int cb, ct;
@@ -598,7 +773,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 template <int C, int BN, bool HAS_RES, int TPW, int CX>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
-  constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 2 * C * 4;
+  constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 3 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX>,
