@@ -169,14 +169,24 @@ int wg_stft_mel(wg_stft* h, const float* mel_basis, int32_t n_mel, const float* 
  * C = n_channels, M8 = 8*n_mel_channels, fl = flow*n_layers + layer, K1 = 3C + M8, h_k / c_k per flow.
  * Needs only wg_create (no wg_set_tensor / wg_finalize). */
 typedef struct wg_train_weights {
-  const void* w1;      /* fp16 [FL][2C][K1]   in_layers (K = tap0 | tap1 | tap2, model.py:98-102) | cond_layer slice */
-  const float* b1;     /* [FL][2C]            in_layers.bias + cond_layer.bias slice */
-  const void* w2;      /* fp16 [FL][C][C]     res rows of res_skip_layers (model.py:131-134); last layer unused */
-  const float* b2;     /* [FL][C] */
-  const void* wes;     /* fp16 [FL][32][C]    end x skip fold: rows 0-7 hi, 8-15 lo fp16 halves of W_end.W_skip_i, rest 0 */
-  const void* wat;     /* fp16 [FL][C][C+64]  backward: [ W_res^T | (W_end.W_skip_i)^T padded to 64 ] */
-  const void* wbt;     /* fp16 [FL][C][6C]    backward: W_in[:, :, tap]^T for tap 0, 1, 2 */
-  const void* wct;     /* fp16 [M8][FL*2C]    backward: cond_layer^T of every layer */
+  /* Forward (one fused launch per WN layer, the inference kernel's structure).  MFMA A-fragment order of that kernel:
+   * NW = wg_wn_waves(C) waves own MB = C/(32 NW) channel blocks each; M tile mt < MB = tanh rows of block w*MB+mt,
+   * mt >= MB = sigmoid rows (+C) of block w*MB+mt-MB; lane (r = lane&31, hh = lane>>5) element j of k16 step
+   * 2*(u&1)+k2 of half K-step u holds  W[row 32*blk + r][64*(u>>1) + 32*(u&1) + 16*k2 + 8*hh + j]  -- rows in NATURAL
+   * channel order, K in position order (tap-major: tap0 | tap1 | tap2, then the cond_layer slice).  The tanh rows and
+   * bias entries are pre-scaled by 2*log2(e), the sigmoid rows by -log2(e) (the gate works on exp2). */
+  const void* a1;      /* fp16 [FL][2*3C/64][NW][2MB][2][64][8]   in_layers (model.py:98-102) */
+  const void* a1c;     /* fp16 [FL][2*M8/64][NW][2MB][2][64][8]   cond_layer slice of the layer (model.py:121-128) */
+  const float* b1;     /* [FL][2C]  (in_layers.bias + cond_layer.bias slice), natural order, pre-scaled */
+  const void* a2;      /* fp16 [FL][NW][MB][C/16][64][8]   res rows of res_skip_layers (model.py:131-134): lane (r, hh)
+                          element j of k16 step k = W_res[32*blk + r][16k + 8hh + j]; last layer of a flow unused */
+  const float* b2;     /* [FL][C] natural order */
+  const void* es;      /* fp16 [FL][C/32][64][8]  end x skip fold W_end.W_skip_i [8][C]: lane (row = lane&15, l4 = lane>>4)
+                          element j of step s = hi (row < 8) / lo (row >= 8) fp16 half of  Wes[row&7][32s + 8 l4 + j] */
+  /* Backward: [rows][K] in "(pos,pos)" order, then in the plane GEMM's fragment order (see above) */
+  const void* wat;     /* fp16 [FL][C][C+64]  [ W_res^T | (W_end.W_skip_i)^T padded to 64 ] */
+  const void* wbt;     /* fp16 [FL][C][6C]    W_in[:, :, tap]^T for tap 0, 1, 2 */
+  const void* wct;     /* fp16 [M8][FL*2C]    cond_layer^T of every layer */
   const void* wup;     /* fp16 [32][M8][512]  upsample per phase p: row (o,g) , K = [tap j][128]: W_up[i][o][8p+g+256j] */
   const float* bup;    /* [M8]                upsample.bias[o] repeated over g */
   const float* const* wstart;    /* n_flows pointers: [C][h_k] fp32 */
@@ -209,6 +219,9 @@ typedef struct wg_train_grads {
 } wg_train_grads;
 
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len);
+
+/* Waves per workgroup of the WN-layer kernel for n_channels (the NW of the fragment orders above); 0 = unsupported. */
+int32_t wg_wn_waves(int32_t n_channels);
 
 /* Forward with saved activations.  mel [B][n_mel][n_frames] fp32, audio [B][audio_len] fp32 (audio_len % 8 == 0),
  * z [B][8][L] fp32 out, log_s[k] [B][h_k][L] fp32 out.  `fresh` != 0: the workspace has not been used with this

@@ -188,6 +188,7 @@ def test_grad_buffers_layout():
   """Every view lies inside its flow's region, views do not overlap, and the regions + tail tile the flat buffer."""
   from waveglow_amd.train import GradBuffers
   b = GradBuffers(device="cpu", **_DP_GEOM)
+  b.flat.zero_()                                                # the buffer is NOT zero-filled by the constructor
   nf, nl = _DP_GEOM["nf"], _DP_GEOM["nl"]
   assert sum(r.numel() for r in b.regions) + b.tail.numel() == b.flat.numel()
   assert b.rec % 4 == 0 and b.flow_stride % 4 == 0              # 16-byte aligned records (float4 stores in the library)

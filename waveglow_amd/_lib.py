@@ -24,7 +24,7 @@ class WgConfig(C.Structure):
 class WgTrainWeights(C.Structure):
   """wg_train_weights (include/waveglow_amd.h): device pointers; the last four are arrays of n_flows pointers."""
   _fields_ = [(n, C.c_void_p) for n in (
-    "w1", "b1", "w2", "b2", "wes", "wat", "wbt", "wct", "wup", "bup", "wstart", "bstart", "out_init", "w1x1")]
+    "a1", "a1c", "b1", "a2", "b2", "es", "wat", "wbt", "wct", "wup", "bup", "wstart", "bstart", "out_init", "w1x1")]
 
 
 class WgTrainGrads(C.Structure):
@@ -64,6 +64,7 @@ SIGNATURES = {
                         C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_macs_per_group_step": (C.c_double, [C.c_void_p]),
   "wg_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+  "wg_wn_waves": (C.c_int32, [C.c_int32]),
   "wg_train_forward": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),

@@ -42,6 +42,19 @@ __device__ __forceinline__ float gate_act(float u, float v) {
   return (e1 - 1.0f) * __builtin_amdgcn_rcpf(fmaf(e1, t, t));
 }
 
+// Training forward: the backward pass needs tanh and sigmoid themselves (train.hip: EPI_DGATE), so all three come out of
+// the same three transcendentals:  r = 1 / ((E1 + 1)(1 + E2)),  acts = (E1 - 1) r,  sigmoid = (E1 + 1) r,
+// tanh = acts (1 + E2).  Both exponents are clamped to +-60 so that every factor stays finite (E2 = inf would make the
+// last product 0 * inf).
+__device__ __forceinline__ void gate_act3(float u, float v, float& th, float& sg, float& ac) {
+  const float e1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(u, -60.0f, 60.0f));
+  const float t = 1.0f + __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(v, -60.0f, 60.0f));
+  const float r = __builtin_amdgcn_rcpf(fmaf(e1, t, t));
+  ac = fmaf(e1, r, -r);
+  sg = fmaf(e1, r, r);
+  th = ac * t;
+}
+
 // ---- hand-counted VMEM in the GEMM main loop (cdna_hip_programming.md 5.7): hipcc drains an LDS-DMA before
 // any later LDS read and sinks register loads next to their use; both serialise the K loop on memory latency.
 // These loads are invisible to the compiler's s_waitcnt bookkeeping; every consumer sits behind wait_vm0*.
@@ -124,7 +137,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // to a [2C x (3 taps x 5)] matrix on the rows of the a0 plane (a0 | 1) that flow_kernel writes next to x_0:
 // 3 K-steps instead of 3C/64 (the bias of start rides on the constant-1 channel, which is 0 in the guard rows, so
 // the convolution's zero padding of x_0 stays exact).
-template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX>
+// TR = training forward (model.py:178-221 under autograd): the conditioning K-steps read the upsampled spectrogram
+// planes a.sp (weights change every optimiser step, so the per-phase cond_layer o upsample fold would have to be rebuilt
+// every step), and the gate also writes tanh, sigmoid and acts as fp16 planes for the backward pass (train.hip).
+template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, bool TR = false>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
   constexpr int MB = C / (32 * NW);      // 32-channel blocks per wave
   constexpr int MT = 2 * MB;             // M tiles per wave: MB tanh blocks, then MB sigmoid blocks
@@ -188,6 +204,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int row = kRowPad + (pp & 31) * Rp + jt * BN + (pp >> 5);
     return (const char*)(a.x_tap + ((size_t)cc * R + row) * 64);
   };
+  // training forward: conditioning K-step s = chunk s of the spectrogram planes, same rows as the centre tap
+  auto sp_src = [&](int p, int jt, int s_) -> const char* {
+    const int row = kRowPad + p * Rp + jt * BN;
+    return (const char*)(a.sp + ((size_t)s_ * R + row) * 64);
+  };
   // Conditioning K-step s (folded cond_layer o upsample, K = 4 taps x M mel channels): column n needs the mel
   // frames q-j, j = 0..3; k index = j*M + i.  Per-lane gather from the frame-major mel (mrow = melT row of the
   // column's frame; 3 for columns outside any utterance: melT rows 0..3 are zero and mrow - j stays in bounds).
@@ -201,6 +222,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #ifndef WG_DBG_NO_DMA
     const unsigned lds = __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16);
     if (ks < NKX) glds16(xstep_src(p, jt, ks), pvoff[i], lds);
+    else if constexpr (TR) glds16(sp_src(p, jt, ks - NKX), pvoff[i], lds);
     else glds16(a.melT, cond_voff(ks - NKX, i), lds);
 #endif
   };
@@ -290,7 +312,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     tile_b0 = rr0 / Fp;
     const int r0 = kRowPad + p * Rp + rr0;            // first plane row of this tile
     const int next_tile = tile + tile_step;
-    wA1c_p = (const char*)a.wA1c + (size_t)p * (2 * a.n_cond_steps) * NW * (NAH * 1024);
+    wA1c_p = (const char*)a.wA1c + (TR ? (size_t)0 : (size_t)p * (2 * a.n_cond_steps) * NW * (NAH * 1024));
     if constexpr (!kXTileDMA) {
       if (it > 0) {
 #pragma unroll
@@ -302,12 +324,14 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
     // mel rows of the frames this lane gathers for the conditioning K-steps
+    if constexpr (!TR) {
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      int b, t;
-      const int rr = rr0 + ((i * NTHREADS + tid) >> 3);
-      const bool ok = column_of(rr, p, b, t);
-      mrow[i] = ok ? 3 + b * mel_rows_per_utt + 3 + (t >> 5) : 3;   // 3: rows 0..3 are zero, and mrow - j >= 0
+      for (int i = 0; i < NG; ++i) {
+        int b, t;
+        const int rr = rr0 + ((i * NTHREADS + tid) >> 3);
+        const bool ok = column_of(rr, p, b, t);
+        mrow[i] = ok ? 3 + b * mel_rows_per_utt + 3 + (t >> 5) : 3;   // 3: rows 0..3 are zero, and mrow - j >= 0
+      }
     }
     WG_STAMP(0);
     // ---- GEMM1 accumulators start from the bias
@@ -361,6 +385,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
       const char* src_next = nullptr;
       if constexpr (more && !ncond) src_next = xstep_src(p, jt, ks + 1);
+      if constexpr (more && ncond && TR) src_next = sp_src(p, jt, ks + 1 - NKX);
       const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
@@ -371,7 +396,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) {
 #ifndef WG_DBG_NO_DMA
             const unsigned lds = __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16);
-            if constexpr (ncond) glds16(a.melT, cond_voff(ks + 1 - NKX, i), lds);
+            if constexpr (ncond && !TR) glds16(a.melT, cond_voff(ks + 1 - NKX, i), lds);
             else glds16(src_next, pvoff[i], lds);
 #endif
           }
@@ -552,9 +577,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       };
       load_xr(0);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c <= NT; ++c) {
-        const bool do_gate = c < NT, do_mm = c >= 1;
+      // one phase; c is a compile-time constant (a plain unrolled loop over c left acc[..][c] dynamically indexed -- in
+      // scratch -- in some instantiations)
+      auto phase = [&](auto c_tag) {
+        constexpr int c = decltype(c_tag)::value;
+        constexpr bool do_gate = c < NT, do_mm = c >= 1;
         f32x16 d2;                                            // GEMM 2 accumulator of chunk c-1: x + b_res + W_res acts
         if (do_mm) {
           const float4* bp = (const float4*)(sBias2 + blk * 32 + 4 * lho);
@@ -574,16 +601,17 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         if (c == NT) es_compute();                            // every acts row is in LDS (barrier of phase NT-1)
         // gate pipeline state (static indices after unrolling)
         float e1[SL], den[SL], rc[SL];
-        half8 o0, o1;
+        half8 o0, o1, th0, th1, sg0, sg1;                     // th / sg: training forward only (saved tanh, sigmoid)
         auto stageA = [&](int e) {
           const int nt = c < NT ? c : 0;
           const float u = __builtin_amdgcn_fmed3f(acc[0][nt][e], -60.0f, 60.0f);
           e1[e] = __builtin_amdgcn_exp2f(u);
-          den[e] = __builtin_amdgcn_exp2f(acc[MB][nt][e]);
+          den[e] = __builtin_amdgcn_exp2f(TR ? __builtin_amdgcn_fmed3f(acc[MB][nt][e], -60.0f, 60.0f) : acc[MB][nt][e]);
         };
         auto stageB = [&](int e) {
           const float t = 1.0f + den[e];
           rc[e] = __builtin_amdgcn_rcpf(fmaf(e1[e], t, t));
+          if constexpr (TR) den[e] = t;
         };
         auto stageC = [&](int e) {
           // (E1 - 1) * rc as ONE fma (exactly rounded once); kept scalar: v_pk_*_f32 costs more per element than a
@@ -591,7 +619,21 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           float v = fmaf(e1[e], rc[e], -rc[e]);
           asm volatile("" : "+v"(v));
           if (e < 8) o0[e] = (_Float16)v; else o1[e - 8] = (_Float16)v;
+          if constexpr (TR) {                                 // gate_act3's sigmoid and tanh from the same factors
+            float sg = fmaf(e1[e], rc[e], rc[e]), th = v * den[e];
+            asm volatile("" : "+v"(sg), "+v"(th));
+            if (e < 8) { sg0[e] = (_Float16)sg; th0[e] = (_Float16)th; } else { sg1[e - 8] = (_Float16)sg; th1[e - 8] = (_Float16)th; }
+          }
         };
+        bool save_ok = false;                                 // training forward: this lane's column of chunk c is a real column
+        size_t save_off = 0;
+        if constexpr (TR) {
+          if (do_gate) {
+            int cb, ct;
+            save_ok = column_of(rr0 + c * 32 + lno, p, cb, ct);
+            save_off = ((size_t)(blk >> 1) * R + r0 + c * 32 + lno) * 64 + (blk & 1) * 32 + lho * 16;
+          }
+        }
         // K2 <= SL (MB == 1: C <= 256): slot i carries the MFMA of k16 step k when k = i*K2/SL changes at i+1
         static_assert(K2 <= SL, "one GEMM-2 MFMA per slot at most");
         half8 bq[K2];
@@ -617,6 +659,20 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if (i & 1) { stageC(i - 1); stageC(i); }
             if (i == 7) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64) = o0;          // positions [32 blk + 16 h, +8)
             if (i == SL - 1) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64 + 16) = o1;
+            if constexpr (TR) {
+              // saved activations: rows of padding columns stay zero (cleared once per workspace geometry), the
+              // weight-gradient kernels sum over every row of a phase
+              if (i == 7 && save_ok) {
+                *(half8*)(a.save_a + save_off) = o0;
+                *(half8*)(a.save_t + save_off) = th0;
+                *(half8*)(a.save_s + save_off) = sg0;
+              }
+              if (i == SL - 1 && save_ok) {
+                *(half8*)(a.save_a + save_off + 8) = o1;
+                *(half8*)(a.save_t + save_off + 8) = th1;
+                *(half8*)(a.save_s + save_off + 8) = sg1;
+              }
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -646,7 +702,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           __builtin_amdgcn_sched_barrier(0);
           if (c == 0) WG_STAMP(3);
         }
-      }
+      };
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      if constexpr (NT >= 2) phase(std::integral_constant<int, 2>{});
+      if constexpr (NT >= 3) phase(std::integral_constant<int, 3>{});
+      if constexpr (NT >= 4) phase(std::integral_constant<int, 4>{});
+      static_assert(NT <= 4, "phases are instantiated explicitly");
       WG_STAMP(4);
     }
     if constexpr (!PIPE) {
@@ -676,10 +738,30 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         half8 o0, o1;
+        if constexpr (TR) {
+          half8 th0, th1, sg0, sg1;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          o0[r] = (_Float16)gate_act(acc[mb][nt][r], acc[MB + mb][nt][r]);
-          o1[r] = (_Float16)gate_act(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r]);
+          for (int r = 0; r < 8; ++r) {
+            float th, sg, ac;
+            gate_act3(acc[mb][nt][r], acc[MB + mb][nt][r], th, sg, ac);
+            o0[r] = (_Float16)ac; th0[r] = (_Float16)th; sg0[r] = (_Float16)sg;
+            gate_act3(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r], th, sg, ac);
+            o1[r] = (_Float16)ac; th1[r] = (_Float16)th; sg1[r] = (_Float16)sg;
+          }
+          int cb, ct;
+          if (column_of(rr0 + nt * 32 + lno, p, cb, ct)) {     // padding columns: rows stay zero (see the pipelined path)
+            const int blk = wave * MB + mb;
+            const size_t off = ((size_t)(blk >> 1) * R + r0 + nt * 32 + lno) * 64 + (blk & 1) * 32 + lho * 16;
+            *(half8*)(a.save_a + off) = o0; *(half8*)(a.save_a + off + 8) = o1;
+            *(half8*)(a.save_t + off) = th0; *(half8*)(a.save_t + off + 8) = th1;
+            *(half8*)(a.save_s + off) = sg0; *(half8*)(a.save_s + off + 8) = sg1;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            o0[r] = (_Float16)gate_act(acc[mb][nt][r], acc[MB + mb][nt][r]);
+            o1[r] = (_Float16)gate_act(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r]);
+          }
         }
         char* ap = acts_lane + nt * 32 * ACT_ROW + (wave * MB + mb) * 64;   // positions [32*blk + 16h, +16)
         *(half8*)(ap) = o0;
@@ -770,13 +852,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   }
 }
 
-template <int C, int BN, bool HAS_RES, int TPW, int CX>
+template <int C, int BN, bool HAS_RES, int TPW, int CX, bool TR = false>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 3 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, TR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
@@ -784,7 +866,7 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   // TPW tiles per workgroup: per XCD label ceil(tiles_on_label / TPW) blocks
   const int per_label = ((a.n_tiles + 7) / 8 + TPW - 1) / TPW;
   const int grid = 8 * per_label;
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX>), dim3(grid), dim3(NW * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, TR>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
 }
 template <int C, int BN, bool HAS_RES, int TPW>
@@ -826,6 +908,26 @@ int wn_waves(int C) {
     case 512: return WnCfg<512>::NW;
   }
   return 0;
+}
+
+// training forward: one tile per workgroup, x_0 planes (no a0 fold), spectrogram planes as the conditioning operand
+template <int C>
+static hipError_t launch_wn_train_t(const WnLayerArgs& a, int bn, hipStream_t s) {
+  if (bn == 64) return a.has_res ? launch_wn_tttt<C, 64, true, 1, C / 64, true>(a, s) : launch_wn_tttt<C, 64, false, 1, C / 64, true>(a, s);
+  if constexpr (WnCfg<C>::BN == 128) {
+    if (bn == 128) return a.has_res ? launch_wn_tttt<C, 128, true, 1, C / 64, true>(a, s) : launch_wn_tttt<C, 128, false, 1, C / 64, true>(a, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_wn_layer_train(const WnLayerArgs& a, int C, int bn, hipStream_t s) {
+  if (!a.sp || !a.save_t || !a.save_s || !a.save_a || a.x_chunks_per_tap != C / 64) return hipErrorInvalidValue;
+  switch (C) {
+    case 64: return launch_wn_train_t<64>(a, bn, s);
+    case 128: return launch_wn_train_t<128>(a, bn, s);
+    case 256: return launch_wn_train_t<256>(a, bn, s);
+    case 512: return launch_wn_train_t<512>(a, bn, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s) {

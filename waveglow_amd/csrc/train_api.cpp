@@ -125,7 +125,7 @@ int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* wo
 
 // every pointer of the weight / gradient blocks that the call sequence dereferences
 int check_weights(const wg_train_weights* w, int n_flows) {
-  if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->wes || !w->wat || !w->wbt || !w->wct || !w->wup || !w->bup ||
+  if (!w->a1 || !w->a1c || !w->b1 || !w->a2 || !w->b2 || !w->es || !w->wat || !w->wbt || !w->wct || !w->wup || !w->bup ||
       !w->wstart || !w->bstart || !w->out_init || !w->w1x1)
     return wg_set_error(WG_ERR_INVALID, "wg_train_weights has a null member");
   for (int k = 0; k < n_flows; ++k)
@@ -161,6 +161,8 @@ int wg_train_debug_stamps(void* device_buffer) {
   return WG_OK;
 }
 
+int32_t wg_wn_waves(int32_t n_channels) { return wn_waves(n_channels); }
+
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
   Ctx x;
   if (setup(const_cast<wg_handle*>(h), B, n_frames, audio_len, nullptr, 0, x) != WG_OK) return 0;
@@ -181,9 +183,24 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
   hipStream_t s = (hipStream_t)stream;
   const int C = x.C, nl = x.nl, M8 = x.M8, K1 = x.K1;
   const int cc = C / 64, mc = M8 / 64;
-  const _Float16* w1 = (const _Float16*)wt->w1;
-  const _Float16* w2 = (const _Float16*)wt->w2;
-  const _Float16* wes = (const _Float16*)wt->wes;
+  // per-layer sizes (fp16 elements) of the forward fragment tensors (include/waveglow_amd.h: wg_train_weights)
+  const int NW = wn_waves(C), MBw = C / (32 * NW), MTw = 2 * MBw;
+  const size_t a1_n = (size_t)2 * (3 * cc) * NW * MTw * 2 * 64 * 8, a1c_n = (size_t)2 * mc * NW * MTw * 2 * 64 * 8;
+  const size_t a2_n = (size_t)NW * MBw * (C / 16) * 64 * 8, es_n = (size_t)(C / 32) * 64 * 8;
+  int n_cu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n_cu = v;
+  }
+  // tile width of the fused layer kernel: as the inference path chooses it (api.cpp: run_wn)
+  int BNw = wn_block_n(C);
+  if (BNw == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)n_cu) BNw = 64;
+  if (const char* e = getenv("WG_FORCE_BN")) {
+    const int f = atoi(e);
+    if (f == 64 || (f == 128 && wn_block_n(C) == 128)) BNw = f;
+  }
+  (void)K1;
 
   if (fresh) TR_TRY(hipMemsetAsync(workspace, 0, w.zero_bytes, s));
   TR_TRY(launch_mel_plane(mel, 0, c.n_mel_channels, g, w.MELP, s));
@@ -247,52 +264,35 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
       const _Float16* Xi = w.X + (size_t)fl * w.plane_c;
       _Float16* Ai = w.A + (size_t)fl * w.plane_c;
       {
-        PGemmArgs a;   // in_layers[i] + cond_layer slice + gate (model.py:123-129)
+        // ONE fused launch per layer (kernels.hip: wn_layer_kernel<..., TR = true>): in_layers[i] + cond_layer slice as one
+        // K-extended GEMM, gate in registers (tanh / sigmoid / acts saved as planes for the backward pass), res rows +
+        // residual add -> x_{i+1}, skip rows folded through WN.end -> OUT   (model.py:123-137)
+        WnLayerArgs a;
         memset(&a, 0, sizeof a);
-        a.n_runs = 4;
-        a.run[0] = run_of(Xi, cc, -d);
-        a.run[1] = run_of(Xi, cc, 0);
-        a.run[2] = run_of(Xi, cc, d);
-        a.run[3] = run_of(w.SP, mc, 0);
-        a.A = w1 + (size_t)fl * 2 * C * K1;
-        a.ktot = K1;
-        a.n_blk = 2 * C / 32;
-        a.M = C;
-        a.bias = wt->b1 + (size_t)fl * 2 * C;
+        a.x_in = Xi;
+        a.x_tap = Xi;
+        a.x_chunks_per_tap = cc;
+        a.x_out = (i < nl - 1) ? w.X + (size_t)(fl + 1) * w.plane_c : nullptr;
+        a.wA1 = (const _Float16*)wt->a1 + (size_t)fl * a1_n;
+        a.wA1c = (const _Float16*)wt->a1c + (size_t)fl * a1c_n;
+        a.bias1 = wt->b1 + (size_t)fl * 2 * C;
+        a.wA2 = (const _Float16*)wt->a2 + (size_t)fl * a2_n;
+        a.bias2 = wt->b2 + (size_t)fl * C;
+        a.wEs = (const _Float16*)wt->es + (size_t)fl * es_n;
+        a.out = w.OUT + (size_t)k * w.rows8;
         a.g = g;
-        a.o0 = w.T + (size_t)fl * w.plane_c;
-        a.o1 = w.S + (size_t)fl * w.plane_c;
-        a.o2 = Ai;
-        TR_TRY(launch_plane_gemm(a, EPI_GATE, s));
-      }
-      if (i < nl - 1) {
-        PGemmArgs a;   // res half of res_skip_layers[i] + residual add (model.py:130-134), and in the same launch
-        memset(&a, 0, sizeof a);   // the skip half folded with WN.end (model.py:135-137): OUT += (W_end W_skip_i) acts
-        a.n_runs = 1;
-        a.run[0] = run_of(Ai, cc, 0);
-        a.A = w2 + (size_t)fl * C * C;
-        a.ktot = C;
-        a.n_blk = C / 32;
-        a.M = C;
-        a.bias = wt->b2 + (size_t)fl * C;
-        a.g = g;
-        a.i0 = Xi;
-        a.o0 = w.X + (size_t)(fl + 1) * w.plane_c;
-        a.A_es = wes + (size_t)fl * 32 * C;
-        a.rows32 = w.OUT + (size_t)k * w.rows8;
-        TR_TRY(launch_plane_gemm(a, EPI_RES, s));
-      } else {
-        PGemmArgs a;   // last layer: no res rows, only the folded end x skip
-        memset(&a, 0, sizeof a);
-        a.n_runs = 1;
-        a.run[0] = run_of(Ai, cc, 0);
-        a.A = wes + (size_t)fl * 32 * C;
-        a.ktot = C;
-        a.n_blk = 1;
-        a.M = 32;
-        a.g = g;
-        a.rows32 = w.OUT + (size_t)k * w.rows8;
-        TR_TRY(launch_plane_gemm(a, EPI_ES, s));
+        a.dil = d;
+        a.n_cond_steps = mc;
+        a.M = c.n_mel_channels;
+        a.has_res = i < nl - 1;
+        a.tiles_per_phase = g.Rp / BNw;
+        a.n_tiles = kPhases * a.tiles_per_phase;
+        a.n_cu = n_cu;
+        a.sp = w.SP;
+        a.save_t = w.T + (size_t)fl * w.plane_c;
+        a.save_s = w.S + (size_t)fl * w.plane_c;
+        a.save_a = Ai;
+        TR_TRY(launch_wn_layer_train(a, C, BNw, s));
       }
     }
   }

@@ -79,6 +79,13 @@ struct WnLayerArgs {
   int n_tiles;              // 32 * tiles_per_phase
   int n_cu;                 // compute units of the device (persistent grid size)
   unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
+  // ---- training forward only (wn_layer_kernel<..., TR = true>, train_api.cpp); null / unused for inference
+  const _Float16* sp;       // upsampled, squeezed spectrogram planes [M8/64 chunks][R][64] (position-major): the B operand
+                            // of the conditioning K-steps (the cond_layer o upsample fold is NOT used: weights change every
+                            // step); wA1c then holds cond_layer's slice itself, no phase dimension, n_cond_steps = M8/64
+  _Float16* save_t;         // saved activations for the backward pass, planes [C/64][R][64] like x:
+  _Float16* save_s;         //   tanh, sigmoid and their product (acts) of this layer
+  _Float16* save_a;
 };
 
 struct MelPackArgs {
@@ -133,6 +140,7 @@ hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* ou
                             int up_kernel, float tanh_scale, float sigm_scale, hipStream_t s);
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
 hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // bn = 128 (default) or 64
+hipError_t launch_wn_layer_train(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // training forward (a.sp, a.save_*)
 int wn_block_n(int C);   // default BN for channel count C
 int wn_waves(int C);     // waves per workgroup for channel count C
 

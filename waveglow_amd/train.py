@@ -90,60 +90,67 @@ def _dense_stack(mods) -> torch.Tensor:
 
 def pack_weights(model) -> Tuple[torch.Tensor, ...]:
   """Differentiable packing of the module's parameters into the stacked matrices of wg_train_weights, in NATURAL
-  channel order (to_pos_order applies the kernels' permutation)."""
+  channel order (to_pos_order applies the kernels' permutation).
+
+  Few, LARGE autograd nodes: modules of one shape are gathered across ALL flows and go through one weight-norm
+  evaluation (``_dense_stack``), and everything per flow (W_end x W_skip fold, start, 1x1) is a batched op over the
+  flow axis -- a per-module formulation costs ~2000 tiny kernels per step (~8 ms of the round-1 step), and every
+  per-layer slice of a big tensor costs a zero-filled full-size gradient in its backward."""
   hp = model._hp
   Cc, nl, nf, M, M8 = hp.n_channels, hp.n_layers, model.n_flows, hp.n_mel_channels, hp.n_mel_channels * 8
-  dev = model.upsample.weight.device
-  pm = _perms(Cc, M8, dev)
-  # Few, large autograd nodes: every per-layer slice of a big tensor costs a zero-filled full-size gradient in its
-  # backward, so layers are stacked first and split once per flow (squeeze is a view, [:, :, 0] a select).
-  w_in, b_in, w_cond, b_cond, w_res, b_res, w_es, start5, out_init, w1x1 = [], [], [], [], [], [], [], [], [], []
   pad = torch.nn.functional.pad
+  WN = model.WN
+  w_in = _dense_stack([WN[k].in_layers[i] for k in range(nf) for i in range(nl)])              # [FL, 2C, C, 3]
+  b_in = torch.stack([WN[k].in_layers[i].bias for k in range(nf) for i in range(nl)])          # [FL, 2C]
+  w_cond = _dense_stack([WN[k].cond_layer for k in range(nf)]).squeeze(3).reshape(nf * nl, 2 * Cc, M8)
+  b_cond = torch.stack([WN[k].cond_layer.bias for k in range(nf)]).reshape(nf * nl, 2 * Cc)
+  last_w = _dense_stack([WN[k].res_skip_layers[nl - 1] for k in range(nf)]).squeeze(3)         # [nf, C, C]: all skip rows
+  last_b = torch.stack([WN[k].res_skip_layers[nl - 1].bias for k in range(nf)])                # [nf, C]
+  if nl > 1:
+    rs_w = _dense_stack([WN[k].res_skip_layers[i] for k in range(nf) for i in range(nl - 1)]).squeeze(3)
+    rs_w = rs_w.view(nf, nl - 1, 2 * Cc, Cc)
+    rs_b = torch.stack([WN[k].res_skip_layers[i].bias for k in range(nf) for i in range(nl - 1)]).view(nf, nl - 1, 2 * Cc)
+    w2 = pad(rs_w[:, :, :Cc], (0, 0, 0, 0, 0, 1)).reshape(nf * nl, Cc, Cc)      # model.py:131-134; the last layer has no res rows
+    b2 = pad(rs_b[:, :, :Cc], (0, 0, 0, 1)).reshape(nf * nl, Cc)
+    w_skips = torch.cat([rs_w[:, :, Cc:], last_w[:, None]], 1)                  # [nf, nl, C, C]   model.py:135-136
+    b_skip_sum = rs_b[:, :, Cc:].sum(1) + last_b                                # [nf, C]
+  else:
+    w2 = torch.zeros_like(last_w)
+    b2 = torch.zeros_like(last_b)
+    w_skips, b_skip_sum = last_w[:, None], last_b
+  # WN.end (not weight-normed, 2h_k rows) zero-padded to 8 rows: end(sum_i skip_i) for every flow in one batched GEMM
+  w_end8 = torch.stack([pad(WN[k].end.weight.squeeze(2), (0, 0, 0, 8 - WN[k].end.weight.shape[0])) for k in range(nf)])
+  b_end8 = torch.stack([pad(WN[k].end.bias, (0, 8 - WN[k].end.bias.shape[0])) for k in range(nf)])
+  wes = torch.matmul(w_end8[:, None], w_skips).reshape(nf * nl, 8, Cc)           # [nf, nl, 8, C]
+  out_init = torch.bmm(w_end8, b_skip_sum[:, :, None]).squeeze(2) + b_end8       # [nf, 8]
+  # start conv [C, h_k] (h_k differs per flow: weight norm per shape group), zero-padded to 4 columns, + bias row
+  by_shape = {}
   for k in range(nf):
-    wn = model.WN[k]
-    h2 = wn.end.weight.shape[0]
-    w_end = wn.end.weight.squeeze(2)                                 # [2h, C]
-    w_cond.append(wn.cond_layer.weight.squeeze(2).view(nl, 2 * Cc, M8))
-    b_cond.append(wn.cond_layer.bias.view(nl, 2 * Cc))
-    w_in.append(_dense_stack(list(wn.in_layers)))                                    # [nl, 2C, C, 3]
-    b_in.append(torch.stack([wn.in_layers[i].bias for i in range(nl)]))
-    last_w, last_b = wn.res_skip_layers[nl - 1].weight.squeeze(2), wn.res_skip_layers[nl - 1].bias   # [C, C]: all skip
-    if nl > 1:
-      rs_w = _dense_stack([wn.res_skip_layers[i] for i in range(nl - 1)]).squeeze(3)                # [nl-1, 2C, C]
-      rs_b = torch.stack([wn.res_skip_layers[i].bias for i in range(nl - 1)])
-      w_res.append(pad(rs_w[:, :Cc], (0, 0, 0, 0, 0, 1)))            # model.py:131-134; the last layer has no res rows
-      b_res.append(pad(rs_b[:, :Cc], (0, 0, 0, 1)))
-      w_skips = torch.cat([rs_w[:, Cc:], last_w[None]])              # model.py:135-136
-      b_skip_sum = rs_b[:, Cc:].sum(0) + last_b
-    else:
-      w_res.append(torch.zeros_like(last_w)[None])
-      b_res.append(torch.zeros_like(last_b)[None])
-      w_skips, b_skip_sum = last_w[None], last_b
-    es = torch.matmul(w_end, w_skips)                                 # end(sum_i skip_i): [nl, 2h, C], one batched GEMM
-    w_es.append(pad(es, (0, 0, 0, 8 - h2)))
-    out_init.append(pad(w_end @ b_skip_sum + wn.end.bias, (0, 8 - h2)))
-    ws = wn.start.weight.squeeze(2)                                   # [C, h]
-    s5 = torch.cat([pad(ws, (0, 4 - ws.shape[1])).t(), wn.start.bias[None, :]], 0)   # [5, C]
-    start5.append(s5)
-    w = model.convinv[k].conv.weight.squeeze(2)
-    w1x1.append(pad(w, (0, 8 - w.shape[1], 0, 8 - w.shape[0])))
+    by_shape.setdefault(tuple(WN[k].start.weight.shape) if not torch.nn.utils.parametrize.is_parametrized(WN[k].start, "weight")
+                        else tuple(WN[k].start.parametrizations.weight.original1.shape), []).append(k)
+  ws_of = {}
+  for ks in by_shape.values():
+    st = _dense_stack([WN[k].start for k in ks]).squeeze(3)                      # [n, C, h]
+    for j, k in enumerate(ks):
+      ws_of[k] = st[j]
+  start5 = torch.stack([torch.cat([pad(ws_of[k], (0, 4 - ws_of[k].shape[1])).t(), WN[k].start.bias[None, :]], 0)
+                        for k in range(nf)])                                     # [nf, 5, C]
+  w1x1 = torch.stack([pad(model.convinv[k].conv.weight.squeeze(2),
+                          (0, 8 - model.convinv[k].conv.weight.shape[1], 0, 8 - model.convinv[k].conv.weight.shape[0]))
+                      for k in range(nf)])
   FL = nf * nl
-  w_in = torch.cat(w_in).permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)        # K = tap-major
-  w1 = torch.cat([w_in, torch.cat(w_cond)], 2)                                  # [FL, 2C, 3C + M8]
+  w_in = w_in.permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)                    # K = tap-major
+  w1 = torch.cat([w_in, w_cond], 2)                                              # [FL, 2C, 3C + M8]
   # "* 1.0": AddBackward hands the SAME gradient tensor to both operands and cat / stack backward only slice it, so
   # in_layers[i].bias.grad and cond_layer.bias.grad would become overlapping views of one buffer (AccumulateGrad
   # installs them without a copy) and the next in-place accumulation would count a gradient twice
-  b1 = torch.cat(b_in) + torch.cat(b_cond) * 1.0
-  w2 = torch.cat(w_res)
-  b2 = torch.cat(b_res)
-  wes = torch.cat(w_es)                                                         # [FL, 8, C]
-  up = model.upsample.weight                                                    # [M_in, M_out, 1024]
-  wup = up.view(M, M, 4, 32, 8).permute(3, 1, 4, 2, 0).reshape(32, M8, 4, M)    # [p][(o,g)][j][i]
+  b1 = b_in + b_cond * 1.0
+  up = model.upsample.weight                                                     # [M_in, M_out, 1024]
+  wup = up.view(M, M, 4, 32, 8).permute(3, 1, 4, 2, 0).reshape(32, M8, 4, M)     # [p][(o,g)][j][i]
   wup = torch.nn.functional.pad(wup, (0, 128 - M)).reshape(32, M8, 512)
   bup = model.upsample.bias.repeat_interleave(8)
   return (w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous(), wes.contiguous(), wup.contiguous(),
-          bup.contiguous(), torch.stack(start5).contiguous(), torch.stack(out_init).contiguous(),
-          torch.stack(w1x1).contiguous())
+          bup.contiguous(), start5.contiguous(), out_init.contiguous(), w1x1.contiguous())
 
 
 def to_fragments(mat: torch.Tensor, c2p: torch.Tensor = None) -> torch.Tensor:
@@ -162,25 +169,57 @@ def _ptr(t: torch.Tensor) -> C.c_void_p:
   return C.c_void_p(t.data_ptr())
 
 
+K_TANH_SCALE = 2.8853900817779268     # 2*log2(e): the gate evaluates tanh / sigmoid through exp2 (kernels.hip: gate_act)
+K_SIGM_SCALE = -1.4426950408889634    # -log2(e)
+
+
+def wn_forward_fragments(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, wes: torch.Tensor, pm: "_Perms", NW: int):
+  """Natural-order stacked matrices -> the forward kernel's operands (include/waveglow_amd.h: wg_train_weights a1, a1c,
+  b1, a2, es): rows stay in natural channel order, K goes to position order, the gate pre-scale is folded into the
+  GEMM-1 rows and bias, and everything is laid out in the WN-layer kernel's MFMA A-fragment order.
+  w1 [FL, 2C, 3C + M8], b1 [FL, 2C], w2 [FL, C, C], wes [FL, 8, C] (fp32)."""
+  FL, C2, K1 = w1.shape
+  Cc = C2 // 2
+  MB = Cc // (32 * NW)
+  nK = K1 // 64
+  scale = torch.cat([torch.full((Cc,), K_TANH_SCALE), torch.full((Cc,), K_SIGM_SCALE)]).to(w1)
+  wk = (w1.index_select(2, pm.k1) * scale[None, :, None]).half()                   # K in position order, rows natural
+  # rows (gate, w, mb, r), K (ks, u1, k2, hh, j)  ->  [ks, u1, w, (gate, mb) = mt, k2, (hh, r) = lane, j]
+  a = wk.reshape(FL, 2, NW, MB, 32, nK, 2, 2, 2, 8).permute(0, 5, 6, 2, 1, 3, 7, 8, 4, 9).contiguous()
+  a = a.reshape(FL, nK, 2 * NW * 2 * MB * 2 * 64 * 8)
+  n_tap = 3 * Cc // 64
+  a1 = a[:, :n_tap].contiguous()
+  a1c = a[:, n_tap:].contiguous()
+  b1s = (b1 * scale[None, :]).float().contiguous()
+  w2k = w2.index_select(2, pm.c).half()                                            # [FL, C rows natural, C pos]
+  a2 = w2k.reshape(FL, NW, MB, 32, Cc // 16, 2, 8).permute(0, 1, 2, 4, 5, 3, 6).contiguous()   # [FL, w, mb, k16, hh, r, j]
+  wek = wes.index_select(2, pm.c)
+  hi = wek.half()
+  lo = (wek - hi.float()).half()
+  rows16 = torch.cat([hi, lo], 1)                                                  # [FL, 16, C pos]
+  es = rows16.reshape(FL, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()  # [FL, s, l4, row, j]: lane = 16 l4 + row
+  return a1, a1c, b1s, a2, es
+
+
 class _Weights:
   """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward)."""
 
-  def __init__(self, model, packed, flow_c: List[int]):
+  def __init__(self, model, packed, flow_c: List[int], NW: int):
     hp = model._hp
     Cc, nf = hp.n_channels, model.n_flows
     dev = packed[0].device
     pm = _perms(Cc, hp.n_mel_channels * 8, dev)
-    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = to_pos_order([t.detach() for t in packed], pm)
+    nat = [t.detach() for t in packed]
+    # forward operands: natural rows, the WN-layer kernel's fragment order
+    self.a1, self.a1c, self.b1, self.a2, self.es = wn_forward_fragments(nat[0], nat[1], nat[2], nat[4], pm, NW)
+    self.b2 = nat[3].float().contiguous()
+    # backward operands: (pos,pos) matrices in the plane GEMM's fragment order
+    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = to_pos_order(nat, pm)
     FL = w1.shape[0]
     r32, c2p = pm.r32, pm.c2p
     w1h, w2h = w1.half(), w2.half()
-    self.b1, self.b2, self.bup = b1.float(), b2.float(), bup.float()
+    self.bup = bup.float()
     hi = wes.half()
-    lo = (wes - hi.float()).half()
-    nat = torch.cat([hi, lo, torch.zeros_like(hi), torch.zeros_like(hi)], 1)     # natural MFMA rows 0..31
-    self.w1 = to_fragments(w1h, c2p)
-    self.w2 = to_fragments(w2h, c2p)
-    self.wes = to_fragments(nat[:, r32], c2p)                   # matrix row chan_to_pos(r) holds MFMA row r
     self.wat = to_fragments(torch.cat([w2h.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2), c2p)
     self.wbt = to_fragments(torch.cat([w1h[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2), c2p)
     self.wct = to_fragments(w1h[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc), c2p)
@@ -191,7 +230,7 @@ class _Weights:
     self.w1x1 = [w1x1[k, :flow_c[k], :flow_c[k]].contiguous().float() for k in range(nf)]
     arr = lambda ts: (C.c_void_p * nf)(*[t.data_ptr() for t in ts])
     self._arrs = [arr(self.wstart), arr(self.bstart), arr(self.out_init), arr(self.w1x1)]
-    self.struct = _lib.WgTrainWeights(_ptr(self.w1), _ptr(self.b1), _ptr(self.w2), _ptr(self.b2), _ptr(self.wes),
+    self.struct = _lib.WgTrainWeights(_ptr(self.a1), _ptr(self.a1c), _ptr(self.b1), _ptr(self.a2), _ptr(self.b2), _ptr(self.es),
                                       _ptr(self.wat), _ptr(self.wbt), _ptr(self.wct), _ptr(self.wup), _ptr(self.bup),
                                       C.cast(self._arrs[0], C.c_void_p), C.cast(self._arrs[1], C.c_void_p),
                                       C.cast(self._arrs[2], C.c_void_p), C.cast(self._arrs[3], C.c_void_p))
@@ -258,7 +297,12 @@ class GradBuffers:
     small = (5 * Cc, 8, 64)
     self.flow_stride = nl * self.rec + sum(small)
     n_tail = 32 * M8 * 512 + M8
-    self.flat = torch.zeros(nf * self.flow_stride + n_tail, dtype=torch.float32, device=device)
+    # Not zero-filled (352 MB per step at 256 channels): the library writes every entry except dw2 / db2 of the last
+    # layer of each flow (no res rows there, model.py:106-110), which are cleared below.  WG_TRAIN_POISON_GRADS=1
+    # (tests) starts from NaN instead, so an entry the library leaves out cannot go unnoticed.
+    self.flat = torch.empty(nf * self.flow_stride + n_tail, dtype=torch.float32, device=device)
+    if os.environ.get("WG_TRAIN_POISON_GRADS") == "1":
+      self.flat.fill_(float("nan"))
     self.regions = [self.flat[k * self.flow_stride:(k + 1) * self.flow_stride] for k in range(nf)]
     self.tail = self.flat[nf * self.flow_stride:]
     st = lambda shape, strides, off: self.flat.as_strided(shape, strides, off)
@@ -275,6 +319,8 @@ class GradBuffers:
     self.dwup = self.tail[:32 * M8 * 512].view(32, M8, 512)
     self.dbup = self.tail[32 * M8 * 512:]
     self.nf = nf
+    self.dw2[:, nl - 1].zero_()
+    self.db2[:, nl - 1].zero_()
 
   def struct(self):
     """(wg_train_grads, keep-alive list)."""
@@ -334,7 +380,10 @@ class _TrainFn(torch.autograd.Function):
     S = audio.shape[1]
     L = S // model.n_group
     flow_c = model.flow_channels()
-    wts = _Weights(model, packed, flow_c)
+    NW = int(lib.wg_wn_waves(model._hp.n_channels))
+    if NW <= 0:
+      raise _lib.WgError(f"n_channels={model._hp.n_channels} unsupported (64, 128, 256, 512)")
+    wts = _Weights(model, packed, flow_c, NW)
     z = torch.empty((B, model.n_group, L), dtype=torch.float32, device=mel.device)
     log_s = [torch.empty((B, c // 2, L), dtype=torch.float32, device=mel.device) for c in flow_c]
     nbytes = lib.wg_train_workspace_bytes(eng.handle, B, F_, S)
