@@ -183,9 +183,14 @@ typedef struct wg_train_weights {
   const float* b2;     /* [FL][C] natural order */
   const void* es;      /* fp16 [FL][C/32][64][8]  end x skip fold W_end.W_skip_i [8][C]: lane (row = lane&15, l4 = lane>>4)
                           element j of step s = hi (row < 8) / lo (row >= 8) fp16 half of  Wes[row&7][32s + 8 l4 + j] */
-  /* Backward: [rows][K] in "(pos,pos)" order, then in the plane GEMM's fragment order (see above) */
-  const void* wat;     /* fp16 [FL][C][C+64]  [ W_res^T | (W_end.W_skip_i)^T padded to 64 ] */
-  const void* wbt;     /* fp16 [FL][C][6C]    W_in[:, :, tap]^T for tap 0, 1, 2 */
+  /* Backward dgrad GEMMs on the same kernel (plain row blocks: [FL][2*K/64][NW][MB][2][64][8], lane (r, hh) element j of
+   * k16 step 2*(u&1)+k2 of half K-step u = Mat[32*blk + r][64*(u>>1) + 32*(u&1) + 16*k2 + 8*hh + j], rows natural, K in
+   * the position order of the planes it multiplies): */
+  const void* wat;     /* fp16, Mat [C][C+64] = [ W_res^T | (W_end.W_skip_i)^T hi halves, padded to 64 ]  (K: d x positions,
+                          then the d out plane's 64 channels) */
+  const void* wbt;     /* fp16, Mat [C][6C]   = W_in[:, :, tap]^T for tap 0, 1, 2  (K per tap: the 2C d-pre positions) */
+  /* ... and on the plane GEMM: [rows][K] in "(pos,pos)" order, fragment order [K/64][rows/32][4][64][8]: lane (r, h)
+   * element j of sub-step s of block b, K-step t = Mat[32b + pos(r)][64t + 32h + 8s + j] */
   const void* wct;     /* fp16 [M8][FL*2C]    cond_layer^T of every layer */
   const void* wup;     /* fp16 [32][M8][512]  upsample per phase p: row (o,g) , K = [tap j][128]: W_up[i][o][8p+g+256j] */
   const float* bup;    /* [M8]                upsample.bias[o] repeated over g */

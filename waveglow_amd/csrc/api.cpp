@@ -600,7 +600,12 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.n_cond_steps = c.n_mel_channels / 16;
     a.M = c.n_mel_channels;
     a.has_res = i < c.n_layers - 1;
+    a.row0 = 0;
     a.tiles_per_phase = g.Rp / BN;
+    a.sp = nullptr;
+    a.save_t = a.save_s = a.save_a = nullptr;
+    a.in0 = a.in1 = nullptr;
+    a.out0 = nullptr;
     a.n_tiles = kPhases * a.tiles_per_phase;
     a.stamps = h->dbg_stamps;
     a.n_cu = h->n_cu;

@@ -140,14 +140,21 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // TR = training forward (model.py:178-221 under autograd): the conditioning K-steps read the upsampled spectrogram
 // planes a.sp (weights change every optimiser step, so the per-phase cond_layer o upsample fold would have to be rebuilt
 // every step), and the gate also writes tanh, sigmoid and acts as fp16 planes for the backward pass (train.hip).
-template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, bool TR = false>
+// MODE 2 / 3 = the two dgrad GEMMs of the backward pass on the same K loop (train_api.cpp): plain row blocks instead of
+// (tanh, sigmoid) pairs, no bias, and a register epilogue instead of gate / GEMM 2 / end x skip:
+//   2  d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t -+ d)        (NTAPS = 3 taps over the 2C d-pre planes, no cond part)
+//   3  d acts = W_res^T d x_{i+1} + (W_end W_skip)^T d out, then the gate derivative -> d pre   (NTAPS = 1: the d x planes,
+//      "cond" part = the d out plane; the last layer of a flow has no d x: one K-step on the d out plane alone)
+template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
+  constexpr bool TR = MODE == 1;         // training forward
+  constexpr bool PLAIN = MODE >= 2;      // backward dgrad GEMMs
   constexpr int MB = C / (32 * NW);      // 32-channel blocks per wave
-  constexpr int MT = 2 * MB;             // M tiles per wave: MB tanh blocks, then MB sigmoid blocks
+  constexpr int MT = PLAIN ? MB : 2 * MB;   // M tiles per wave: MB tanh blocks, then MB sigmoid blocks (PLAIN: MB row blocks)
   constexpr int NTHREADS = NW * 64;
   constexpr int NT = BN / 32;            // 32-column MFMA tiles per wave
   constexpr int CC = CX;                 // 64-channel chunks per tap of the GEMM-1 B operand (a.x_tap)
-  constexpr int NKX = 3 * CC;            // K-steps of the three dilated taps
+  constexpr int NKX = NTAPS * CC;        // K-steps of the dilated taps
   constexpr int BT_BYTES = BN * 128;     // one staged B tile: BN rows x 64 fp16
   constexpr int ACT_ROW = 2 * C + 16;    // bytes per acts row: +16 B pad => conflict-free b128 reads/writes with
                                          // immediate-offset addressing (one base VGPR per 32-column tile)
@@ -155,7 +162,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NG = BN * 8 / NTHREADS;  // LDS-DMA instructions per wave per B tile
   constexpr int NAH = MT * 2;            // A fragments per half K-step (packing unit)
   constexpr bool DEFER = (MB == 1);      // defer a step's last sub-step past the barrier (needs spare registers)
-  static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 3, "tile geometry");
+  static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 1 && (NTAPS == 1 || NTAPS == 3), "tile geometry");
+  static_assert(MODE == 0 || (TPW == 1 && CX == (MODE == 2 ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sB = smem;                     // 2 x BT_BYTES
@@ -192,7 +200,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   set_lane_ids();
   const unsigned sB_addr = (unsigned)(size_t)WG_LPTR(sB);
   const int R = a.g.R, Rp = a.g.Rp, Fp = a.g.Fp, M = a.M;
-  const int nK = NKX + a.n_cond_steps;
+  const int nK = NKX + (HAS_COND ? a.n_cond_steps : 0);
   const int mel_rows_per_utt = a.g.T + 6;
 
   // Tile = (phase p, BN consecutive rows of that phase's block).  Row of column n: kRowPad + p*Rp + jt*BN + n.
@@ -200,13 +208,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   // (p+delta)&31 and the frame by (p+delta)>>5 -- again BN contiguous rows (model.py:98-102: padding = dilation).
   auto xstep_src = [&](int p, int jt, int ks) -> const char* {
     const int tap = ks / CC, cc = ks - tap * CC;
-    const int pp = p + (tap - 1) * a.dil;
-    const int row = kRowPad + (pp & 31) * Rp + jt * BN + (pp >> 5);
+    const int pp = p + (tap - NTAPS / 2) * a.dil;
+    const int row = kRowPad + (pp & 31) * Rp + a.row0 + jt * BN + (pp >> 5);
     return (const char*)(a.x_tap + ((size_t)cc * R + row) * 64);
   };
   // training forward: conditioning K-step s = chunk s of the spectrogram planes, same rows as the centre tap
   auto sp_src = [&](int p, int jt, int s_) -> const char* {
-    const int row = kRowPad + p * Rp + jt * BN;
+    const int row = kRowPad + p * Rp + a.row0 + jt * BN;
     return (const char*)(a.sp + ((size_t)s_ * R + row) * 64);
   };
   // Conditioning K-step s (folded cond_layer o upsample, K = 4 taps x M mel channels): column n needs the mel
@@ -222,7 +230,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #ifndef WG_DBG_NO_DMA
     const unsigned lds = __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16);
     if (ks < NKX) glds16(xstep_src(p, jt, ks), pvoff[i], lds);
-    else if constexpr (TR) glds16(sp_src(p, jt, ks - NKX), pvoff[i], lds);
+    else if constexpr (MODE != 0) glds16(sp_src(p, jt, ks - NKX), pvoff[i], lds);
     else glds16(a.melT, cond_voff(ks - NKX, i), lds);
 #endif
   };
@@ -289,9 +297,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 
   // bias of GEMM1 (pre-scaled: in_layer bias + cond_layer bias slice + W_cond . upsample bias), fp32 [2C], in LDS
   float* const sBias = (float*)(sActs + BN * ACT_ROW);
-  for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
-  if constexpr (HAS_RES)
-    for (int i = tid; i < C; i += NTHREADS) sBias[2 * C + i] = a.bias2[i];   // b_res, read by the pipelined epilogue
+  if constexpr (!PLAIN) {
+    for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
+    if constexpr (HAS_RES)
+      for (int i = tid; i < C; i += NTHREADS) sBias[2 * C + i] = a.bias2[i];   // b_res, read by the pipelined epilogue
+  }
 
   half8 q[4][MT];
   int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
@@ -308,11 +318,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     if (it > 0) set_lane_ids();
     const int p = tile / a.tiles_per_phase;           // phase of every column of this tile
     const int jt = tile - p * a.tiles_per_phase;
-    const int rr0 = jt * BN;                          // first row inside the phase block
+    const int rr0 = a.row0 + jt * BN;                 // first row inside the phase block
     tile_b0 = rr0 / Fp;
     const int r0 = kRowPad + p * Rp + rr0;            // first plane row of this tile
     const int next_tile = tile + tile_step;
-    wA1c_p = (const char*)a.wA1c + (TR ? (size_t)0 : (size_t)p * (2 * a.n_cond_steps) * NW * (NAH * 1024));
+    wA1c_p = (const char*)a.wA1c + (MODE != 0 ? (size_t)0 : (size_t)p * (2 * a.n_cond_steps) * NW * (NAH * 1024));
     if constexpr (!kXTileDMA) {
       if (it > 0) {
 #pragma unroll
@@ -324,7 +334,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
     // mel rows of the frames this lane gathers for the conditioning K-steps
-    if constexpr (!TR) {
+    if constexpr (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < NG; ++i) {
         int b, t;
@@ -338,13 +348,18 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int row0 = (mt < MB ? 0 : C) + (wave * MB + (mt < MB ? mt : mt - MB)) * 32;
-      const float4* bp = (const float4*)(sBias + row0 + 4 * lh);
       f32x16 v;
+      if constexpr (PLAIN) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 q4 = bp[2 * g];
-        v[4 * g] = q4.x; v[4 * g + 1] = q4.y; v[4 * g + 2] = q4.z; v[4 * g + 3] = q4.w;
+        for (int j = 0; j < 16; ++j) v[j] = 0.0f;
+      } else {
+        const int row0 = (mt < MB ? 0 : C) + (wave * MB + (mt < MB ? mt : mt - MB)) * 32;
+        const float4* bp = (const float4*)(sBias + row0 + 4 * lh);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 q4 = bp[2 * g];
+          v[4 * g] = q4.x; v[4 * g + 1] = q4.y; v[4 * g + 2] = q4.z; v[4 * g + 3] = q4.w;
+        }
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v;
@@ -385,7 +400,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
       const char* src_next = nullptr;
       if constexpr (more && !ncond) src_next = xstep_src(p, jt, ks + 1);
-      if constexpr (more && ncond && TR) src_next = sp_src(p, jt, ks + 1 - NKX);
+      if constexpr (more && ncond && MODE != 0) src_next = sp_src(p, jt, ks + 1 - NKX);
       const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
@@ -396,7 +411,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           for (int i = nt * GPS; i < (nt + 1) * GPS && i < NG; ++i) {
 #ifndef WG_DBG_NO_DMA
             const unsigned lds = __builtin_amdgcn_readfirstlane(lds_next + i * NTHREADS * 16);
-            if constexpr (ncond && !TR) glds16(a.melT, cond_voff(ks + 1 - NKX, i), lds);
+            if constexpr (ncond && MODE == 0) glds16(a.melT, cond_voff(ks + 1 - NKX, i), lds);
             else glds16(src_next, pvoff[i], lds);
 #endif
           }
@@ -446,13 +461,21 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     {
       using T_ = std::true_type;
       using F_ = std::false_type;
-      kstep(T_{}, F_{}, T_{}, 0);                                   // tap steps 0 .. NKX-2: next is a tap step
+      if constexpr (NKX == 1) {
+        if constexpr (HAS_COND) kstep(T_{}, T_{}, T_{}, 0);         // the only tap step: next is conditioning
+        else kstep(F_{}, F_{}, T_{}, 0);                            // the only step
+      } else {
+        kstep(T_{}, F_{}, T_{}, 0);                                 // tap steps 0 .. NKX-2: next is a tap step
 #pragma clang loop unroll(disable)
-      for (int ks = 1; ks < NKX - 1; ++ks) kstep(T_{}, F_{}, F_{}, ks);
-      kstep(T_{}, T_{}, F_{}, NKX - 1);                             // last tap step: next is conditioning
+        for (int ks = 1; ks < NKX - 1; ++ks) kstep(T_{}, F_{}, F_{}, ks);
+        if constexpr (HAS_COND) kstep(T_{}, T_{}, F_{}, NKX - 1);   // last tap step: next is conditioning
+        else kstep(F_{}, F_{}, F_{}, NKX - 1);                      // last step
+      }
+      if constexpr (HAS_COND) {
 #pragma clang loop unroll(disable)
-      for (int ks = NKX; ks < nK - 1; ++ks) kstep(T_{}, T_{}, F_{}, ks);
-      kstep(F_{}, F_{}, F_{}, nK - 1);                              // last conditioning step
+        for (int ks = NKX; ks < nK - 1; ++ks) kstep(T_{}, T_{}, F_{}, ks);
+        kstep(F_{}, F_{}, F_{}, nK - 1);                            // last conditioning step
+      }
     }
     if constexpr (DEFER) {
       wait_vm<0>();                          // q[3] of the last step
@@ -473,6 +496,54 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     __builtin_amdgcn_sched_barrier(0);
 
     WG_STAMP(2);
+    if constexpr (PLAIN) {
+      // ---- backward dgrad epilogues: lane (column n = ln of N tile nt, half h) holds rows (= storage positions)
+      // [32 blk + 16 h, +16) of its column, 32 contiguous bytes of every fp16 plane.  Only real columns are written:
+      // rows of padding columns stay zero (cleared once per workspace geometry), the weight-gradient kernels sum over them.
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int cb, ct;
+        if (!column_of(rr0 + nt * 32 + ln, p, cb, ct)) continue;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int blk = wave * MB + mb;
+          const size_t off = ((size_t)(blk >> 1) * R + r0 + nt * 32 + ln) * 64 + (blk & 1) * 32 + lh * 16;
+          half8 o0, o1;
+          if constexpr (MODE == 2) {
+            // d x_i = d x_{i+1} (residual path, model.py:131-132) + the three taps' contributions
+            half8 i0, i1;
+            if (a.in0) { i0 = *(const half8*)(a.in0 + off); i1 = *(const half8*)(a.in0 + off + 8); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              o0[r] = (_Float16)(acc[mb][nt][r] + (a.in0 ? (float)i0[r] : 0.0f));
+              o1[r] = (_Float16)(acc[mb][nt][8 + r] + (a.in0 ? (float)i1[r] : 0.0f));
+            }
+            *(half8*)(a.out0 + off) = o0;
+            *(half8*)(a.out0 + off + 8) = o1;
+          } else {
+            // gate derivative (model.py:17-19): d u = g S (1 - T^2), d v = g T S (1 - S) -> the 2C d-pre planes
+            const half8 t0 = *(const half8*)(a.in0 + off), t1 = *(const half8*)(a.in0 + off + 8);
+            const half8 s0 = *(const half8*)(a.in1 + off), s1 = *(const half8*)(a.in1 + off + 8);
+            half8 p0, p1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const float ta = (float)t0[r], sa = (float)s0[r], ga = acc[mb][nt][r];
+              const float tb = (float)t1[r], sb = (float)s1[r], gb = acc[mb][nt][8 + r];
+              o0[r] = (_Float16)(ga * sa * (1.0f - ta * ta));
+              o1[r] = (_Float16)(gb * sb * (1.0f - tb * tb));
+              p0[r] = (_Float16)(ga * ta * sa * (1.0f - sa));
+              p1[r] = (_Float16)(gb * tb * sb * (1.0f - sb));
+            }
+            const size_t off_s = off + (size_t)(C / 64) * R * 64;      // the sigmoid half: chunks C/64 .. 2C/64-1
+            *(half8*)(a.out0 + off) = o0;
+            *(half8*)(a.out0 + off + 8) = o1;
+            *(half8*)(a.out0 + off_s) = p0;
+            *(half8*)(a.out0 + off_s + 8) = p1;
+          }
+        }
+      }
+    }
+    if constexpr (!PLAIN) {
     // Per-tile opaque copies of the lane ids: every address / weight load of the phases below depends on them,
     // so hipcc cannot hoist those (tile-invariant) values out of the tile bodies and spill them
     // (a spill reload is a VMEM op whose compiler-inserted vmcnt(0) would drain the hand-placed prefetches).
@@ -848,17 +919,18 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     }
     WG_STAMP(6);
+    }   // !PLAIN
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's prologue (128 accumulator inits) out of this epilogue
   }
 }
 
-template <int C, int BN, bool HAS_RES, int TPW, int CX, bool TR = false>
+template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
-  constexpr int smem = 2 * BN * 128 + BN * (2 * C + 16) + 3 * C * 4;
+  constexpr int smem = 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, TR>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
@@ -866,7 +938,7 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   // TPW tiles per workgroup: per XCD label ceil(tiles_on_label / TPW) blocks
   const int per_label = ((a.n_tiles + 7) / 8 + TPW - 1) / TPW;
   const int grid = 8 * per_label;
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, TR>), dim3(grid), dim3(NW * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
 }
 template <int C, int BN, bool HAS_RES, int TPW>
@@ -913,9 +985,9 @@ int wn_waves(int C) {
 // training forward: one tile per workgroup, x_0 planes (no a0 fold), spectrogram planes as the conditioning operand
 template <int C>
 static hipError_t launch_wn_train_t(const WnLayerArgs& a, int bn, hipStream_t s) {
-  if (bn == 64) return a.has_res ? launch_wn_tttt<C, 64, true, 1, C / 64, true>(a, s) : launch_wn_tttt<C, 64, false, 1, C / 64, true>(a, s);
+  if (bn == 64) return a.has_res ? launch_wn_tttt<C, 64, true, 1, C / 64, 1>(a, s) : launch_wn_tttt<C, 64, false, 1, C / 64, 1>(a, s);
   if constexpr (WnCfg<C>::BN == 128) {
-    if (bn == 128) return a.has_res ? launch_wn_tttt<C, 128, true, 1, C / 64, true>(a, s) : launch_wn_tttt<C, 128, false, 1, C / 64, true>(a, s);
+    if (bn == 128) return a.has_res ? launch_wn_tttt<C, 128, true, 1, C / 64, 1>(a, s) : launch_wn_tttt<C, 128, false, 1, C / 64, 1>(a, s);
   }
   return hipErrorInvalidValue;
 }
@@ -926,6 +998,37 @@ hipError_t launch_wn_layer_train(const WnLayerArgs& a, int C, int bn, hipStream_
     case 128: return launch_wn_train_t<128>(a, bn, s);
     case 256: return launch_wn_train_t<256>(a, bn, s);
     case 512: return launch_wn_train_t<512>(a, bn, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// backward dgrad GEMMs on the WN-layer K loop.  kind 2: d x (3 taps over the 2C d-pre planes); kind 3: d acts + gate
+// derivative (a.x_tap = d x planes + a.sp = d out plane, or -- a.x_tap == a.sp's plane alone -- the last layer of a flow)
+template <int C>
+static hipError_t launch_wn_plain_t(const WnLayerArgs& a, int kind, int bn, hipStream_t s) {
+  constexpr int CCH = C / 64;
+  if constexpr (WnCfg<C>::BN == 128) {
+    if (bn == 128) {
+      if (kind == 2) return launch_wn_tttt<C, 128, false, 1, 2 * CCH, 2, 3, false>(a, s);
+      if (a.x_chunks_per_tap == 1 && a.n_cond_steps == 0) return launch_wn_tttt<C, 128, false, 1, 1, 3, 1, false>(a, s);
+      return launch_wn_tttt<C, 128, false, 1, CCH, 3, 1, true>(a, s);
+    }
+  }
+  if (bn != 64) return hipErrorInvalidValue;
+  if (kind == 2) return launch_wn_tttt<C, 64, false, 1, 2 * CCH, 2, 3, false>(a, s);
+  if (a.x_chunks_per_tap == 1 && a.n_cond_steps == 0) return launch_wn_tttt<C, 64, false, 1, 1, 3, 1, false>(a, s);
+  return launch_wn_tttt<C, 64, false, 1, CCH, 3, 1, true>(a, s);
+}
+hipError_t launch_wn_plain(const WnLayerArgs& a, int C, int kind, int bn, hipStream_t s) {
+  if ((kind != 2 && kind != 3) || !a.out0 || !a.x_tap || (kind == 3 && (!a.in0 || !a.in1))) return hipErrorInvalidValue;
+  if (kind == 2 && (a.x_chunks_per_tap != 2 * (C / 64) || a.n_cond_steps != 0)) return hipErrorInvalidValue;
+  if (kind == 3 && !((a.x_chunks_per_tap == 1 && a.n_cond_steps == 0) || (a.x_chunks_per_tap == C / 64 && a.n_cond_steps == 1 && a.sp)))
+    return hipErrorInvalidValue;
+  switch (C) {
+    case 64: return launch_wn_plain_t<64>(a, kind, bn, s);
+    case 128: return launch_wn_plain_t<128>(a, kind, bn, s);
+    case 256: return launch_wn_plain_t<256>(a, kind, bn, s);
+    case 512: return launch_wn_plain_t<512>(a, kind, bn, s);
   }
   return hipErrorInvalidValue;
 }

@@ -143,6 +143,19 @@ int check_grads(const wg_train_grads* g, int n_flows) {
   return WG_OK;
 }
 
+// One WN-layer-kernel GEMM over every column of the planes.  (Measured and dropped: splitting a layer whose tile count
+// is not a multiple of the CU count -- config 4: 576 tiles of 128 columns = 2.25 rounds -- into a whole-rounds launch of
+// 128-column tiles and a tail launch of 64-column tiles.  A 64-column tile streams the same A fragments and takes ~80 % of
+// a 128-column tile's time (the K loop is VMEM-issue bound), so 2 + 0.8 rounds plus a second launch is no faster than 3.)
+template <class Launch>
+hipError_t launch_rounds(WnLayerArgs a, const RowGeom& g, int bn, int n_cu, Launch launch) {
+  (void)n_cu;
+  a.row0 = 0;
+  a.tiles_per_phase = g.Rp / bn;
+  a.n_tiles = kPhases * a.tiles_per_phase;
+  return launch(a, bn);
+}
+
 PRun run_of(const _Float16* base, int n_chunks, int dt) {
   PRun r;
   r.base = base;
@@ -285,14 +298,12 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.n_cond_steps = mc;
         a.M = c.n_mel_channels;
         a.has_res = i < nl - 1;
-        a.tiles_per_phase = g.Rp / BNw;
-        a.n_tiles = kPhases * a.tiles_per_phase;
         a.n_cu = n_cu;
         a.sp = w.SP;
         a.save_t = w.T + (size_t)fl * w.plane_c;
         a.save_s = w.S + (size_t)fl * w.plane_c;
         a.save_a = Ai;
-        TR_TRY(launch_wn_layer_train(a, C, BNw, s));
+        TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_layer_train(q, C, bn, s); }));
       }
     }
   }
@@ -329,6 +340,22 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   const int small_split = 4;                           // Rp is a multiple of 128 = 4 parts of whole 32-row steps
   const _Float16* wat = (const _Float16*)wt->wat;
   const _Float16* wbt = (const _Float16*)wt->wbt;
+  // fragment tensors of the two dgrad GEMMs (include/waveglow_amd.h: wat, wbt): elements per 64-deep K-step and per layer
+  const int NW = wn_waves(C), MBw = C / (32 * NW);
+  const size_t kstep_n = (size_t)2 * NW * MBw * 2 * 64 * 8;
+  const size_t wat_n = (size_t)(cc + 1) * kstep_n, wbt_n = (size_t)(6 * cc) * kstep_n;
+  int n_cu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n_cu = v;
+  }
+  int BNw = wn_block_n(C);
+  if (BNw == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)n_cu) BNw = 64;
+  if (const char* e = getenv("WG_FORCE_BN")) {
+    const int f = atoi(e);
+    if (f == 64 || (f == 128 && wn_block_n(C) == 128)) BNw = f;
+  }
   // where entry fl of a per-layer gradient tensor lives: dense, or in interleaved per-layer records (wg_train_grads)
   if ((gr->layer_stride == 0) != (gr->flow_stride == 0) || gr->layer_stride < 0 || gr->flow_stride < 0)
     return wg_set_error(WG_ERR_INVALID, "wg_train_grads: layer_stride and flow_stride must both be 0 or both positive");
@@ -373,28 +400,32 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
       const _Float16* Ai = w.A + (size_t)fl * w.plane_c;
       _Float16* GPi = w.GP + (size_t)fl * 2 * w.plane_c;
       {
-        PGemmArgs a;   // d acts = W_res^T d x_{i+1} + (W_end W_skip_i)^T d out ; gate derivative -> d pre
+        // d acts = W_res^T d x_{i+1} + (W_end W_skip_i)^T d out ; gate derivative -> d pre   (wn_layer_kernel MODE 3)
+        WnLayerArgs a;
         memset(&a, 0, sizeof a);
-        const _Float16* Am = wat + (size_t)fl * C * (C + 64);
+        const _Float16* Am = wat + (size_t)fl * wat_n;
         if (gx) {
-          a.n_runs = 2;
-          a.run[0] = run_of(gx, cc, 0);
-          a.run[1] = run_of(w.GO, 1, 0);
-          a.A = Am;
-          a.ktot = C + 64;
+          a.x_tap = gx;
+          a.x_chunks_per_tap = cc;
+          a.sp = w.GO;
+          a.n_cond_steps = 1;
+          a.wA1 = Am;
+          a.wA1c = Am + (size_t)cc * kstep_n;
         } else {
-          a.n_runs = 1;
-          a.run[0] = run_of(w.GO, 1, 0);
-          a.A = Am + (size_t)(C / 64) * (C / 32) * 2048;   // skip the K-steps of the (absent) d x_{i+1} run
-          a.ktot = 64;
+          a.x_tap = w.GO;                    // last layer of a flow: no d x_{i+1}, the d out plane alone
+          a.x_chunks_per_tap = 1;
+          a.n_cond_steps = 0;
+          a.wA1 = Am + (size_t)cc * kstep_n;
+          a.wA1c = a.wA1;
         }
-        a.n_blk = C / 32;
-        a.M = C;
+        a.dil = 0;
         a.g = g;
-        a.i0 = w.T + (size_t)fl * w.plane_c;
-        a.i1 = w.S + (size_t)fl * w.plane_c;
-        a.o0 = GPi;
-        TR_TRY(launch_plane_gemm(a, EPI_DGATE, s));
+        a.M = c.n_mel_channels;
+        a.n_cu = n_cu;
+        a.in0 = w.T + (size_t)fl * w.plane_c;
+        a.in1 = w.S + (size_t)fl * w.plane_c;
+        a.out0 = GPi;
+        TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, s); }));
       }
       {
         WgradArgs a;   // d W1 = d pre x [x taps | spect]^T, d b1
@@ -446,20 +477,21 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         if (i == 0) TR_TRY(launch_slab_reduce(w.part + (size_t)gc * 64, ns, bias_n, 8, inv, gr->dout_init[k], s));
       }
       {
-        PGemmArgs a;   // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)
+        // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)   (wn_layer_kernel MODE 2: taps at +d, 0, -d)
+        WnLayerArgs a;
         memset(&a, 0, sizeof a);
-        a.n_runs = 3;
-        a.run[0] = run_of(GPi, 2 * cc, d);
-        a.run[1] = run_of(GPi, 2 * cc, 0);
-        a.run[2] = run_of(GPi, 2 * cc, -d);
-        a.A = wbt + (size_t)fl * C * 6 * C;
-        a.ktot = 6 * C;
-        a.n_blk = C / 32;
-        a.M = C;
+        a.x_tap = GPi;
+        a.x_chunks_per_tap = 2 * cc;
+        a.n_cond_steps = 0;
+        a.wA1 = wbt + (size_t)fl * wbt_n;
+        a.wA1c = a.wA1;
+        a.dil = -d;
         a.g = g;
-        a.i0 = gx;
-        a.o0 = gx_next;
-        TR_TRY(launch_plane_gemm(a, EPI_RES, s));
+        a.M = c.n_mel_channels;
+        a.n_cu = n_cu;
+        a.in0 = gx;
+        a.out0 = gx_next;
+        TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 2, bn, s); }));
         gx = gx_next;
         gx_next = (gx == w.GX0) ? w.GX1 : w.GX0;
       }

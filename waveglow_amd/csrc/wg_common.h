@@ -75,7 +75,9 @@ struct WnLayerArgs {
   int n_cond_steps;         // K-steps of the folded conditioning = 4*M/64 = M/16
   int M;                    // n_mel_channels
   int has_res;              // 0 for the last layer of a WN (model.py:106-110)
-  int tiles_per_phase;      // Rp / BN
+  int row0;                 // first row (inside every phase block) of this launch's tiles: 0, or the start of the narrow-tile
+                            // tail when a layer is split into a wide-tile and a narrow-tile launch (train_api.cpp)
+  int tiles_per_phase;      // tiles of this launch per phase: (Rp - row0) / BN, or fewer
   int n_tiles;              // 32 * tiles_per_phase
   int n_cu;                 // compute units of the device (persistent grid size)
   unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
@@ -86,6 +88,10 @@ struct WnLayerArgs {
   _Float16* save_t;         // saved activations for the backward pass, planes [C/64][R][64] like x:
   _Float16* save_s;         //   tanh, sigmoid and their product (acts) of this layer
   _Float16* save_a;
+  // ---- backward dgrad GEMMs only (MODE 2 / 3, launch_wn_plain): epilogue inputs / output planes
+  const _Float16* in0;      // MODE 2: d x_{i+1} planes added to the result (or null); MODE 3: saved tanh planes
+  const _Float16* in1;      // MODE 3: saved sigmoid planes
+  _Float16* out0;           // MODE 2: d x_i planes [C/64]; MODE 3: d pre planes [2C/64] (tanh half, then sigmoid half)
 };
 
 struct MelPackArgs {
@@ -141,6 +147,7 @@ hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* ou
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
 hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // bn = 128 (default) or 64
 hipError_t launch_wn_layer_train(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // training forward (a.sp, a.save_*)
+hipError_t launch_wn_plain(const WnLayerArgs& a, int C, int kind, int bn, hipStream_t s);   // backward dgrad GEMMs (kind 2 / 3)
 int wn_block_n(int C);   // default BN for channel count C
 int wn_waves(int C);     // waves per workgroup for channel count C
 

@@ -201,6 +201,15 @@ def wn_forward_fragments(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, w
   return a1, a1c, b1s, a2, es
 
 
+def plain_fragments(mat: torch.Tensor, NW: int) -> torch.Tensor:
+  """[FL, M, K] fp16 (rows natural, K already in the order of the planes it multiplies) -> the WN-layer kernel's A-fragment
+  order for plain row blocks [FL, K/64, 2, NW, MB, 2, 64, 8] (include/waveglow_amd.h: wat, wbt)."""
+  FL, M, K = mat.shape
+  MB = M // (32 * NW)
+  v = mat.reshape(FL, NW, MB, 32, K // 64, 2, 2, 2, 8)                      # rows (w, mb, r), K (ks, u1, k2, hh, j)
+  return v.permute(0, 4, 5, 1, 2, 6, 7, 3, 8).contiguous()                  # [FL, ks, u1, w, mb, k2, hh, r, j]
+
+
 class _Weights:
   """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward)."""
 
@@ -219,9 +228,13 @@ class _Weights:
     r32, c2p = pm.r32, pm.c2p
     w1h, w2h = w1.half(), w2.half()
     self.bup = bup.float()
-    hi = wes.half()
-    self.wat = to_fragments(torch.cat([w2h.transpose(1, 2), torch.nn.functional.pad(hi, (0, 0, 0, 56)).transpose(1, 2)], 2), c2p)
-    self.wbt = to_fragments(torch.cat([w1h[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2) for t in range(3)], 2), c2p)
+    # dgrad GEMMs (WN-layer kernel, plain rows): rows natural, K in the position order of the gradient planes
+    n_w1, n_w2, n_wes = nat[0], nat[2], nat[4]
+    wat_m = torch.cat([n_w2.transpose(1, 2).index_select(2, pm.c),                          # [FL, C acts, C d-x positions]
+                       torch.nn.functional.pad(n_wes.half().float(), (0, 0, 0, 56)).transpose(1, 2)], 2)   # | 64 d-out channels
+    self.wat = plain_fragments(wat_m.half(), NW)
+    self.wbt = plain_fragments(torch.cat([n_w1[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2).index_select(2, pm.c2)
+                                          for t in range(3)], 2).half(), NW)
     self.wct = to_fragments(w1h[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc), c2p)
     self.wup = to_fragments(wup.half(), c2p)
     self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
