@@ -125,6 +125,24 @@ def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
                     f"{best:.2f} s ({spent:.1f} s of CPU work in all)"}
 
 
+def train_roofline(hp, B, S, steps, ms, cnt):
+  """Roofline block of the training line: the dominant kernel is wgrad_kernel (weight gradients: dW = G^T X over all
+  columns, MFMA-bound).  Algorithmic FLOPs per step = 2 x columns x sum over the layers of the weight matrices' sizes
+  (in_layers + cond_layer slice [2C x (3C + M8)], res rows [C x C] except in a flow's last layer, end x skip [8 x C]),
+  plus the upsample filter per phase [M8 x 4M]; time = hipEvents around the launches (classes of wg_profile_read)."""
+  C_, nl, nf, M8 = hp.n_channels, hp.n_layers, hp.n_flows, hp.n_mel_channels * 8
+  cols = B * (S // hp.n_group)
+  per_flow = nl * (2 * C_ * (3 * C_ + M8) + 8 * C_) + (nl - 1) * C_ * C_
+  flops = 2.0 * cols * (nf * per_flow + M8 * 4 * hp.n_mel_channels)
+  t_wgrad = ms[6] / steps * 1e-3
+  achieved = flops / t_wgrad / 1e12 if t_wgrad > 0 else 0.0
+  n = max(1, int(cnt[6]))
+  return {"bound": "mfma", "kernel": "wgrad_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP16_DENSE_TFLOPS,
+          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4), "traffic": None,
+          "avg_launch_ms": round(ms[6] / n, 4), "launches_timed": int(cnt[6]), "algorithmic_flops_per_step": flops,
+          "kernel_ms_per_step": {"wgrad": round(ms[6] / steps, 3)}}
+
+
 def bench_train(args, rank, world, dev, dist):
   """BASELINE configs[3]: the training step of src/waveglow/train.py:190-199 (forward, WaveGlowLoss, backward, Adam),
   data-parallel: per-GPU batch fixed (weak scaling), gradients averaged by one bucketed all-reduce per step."""
@@ -159,6 +177,8 @@ def bench_train(args, rank, world, dev, dist):
 
   for _ in range(args.warmup):
     loss = step()
+  eng = model._engine
+  eng.lib.wg_profile_enable(eng.handle, 1 << 6)  # hipEvents around the wgrad launches only (one pair per launch), on their stream
   torch.cuda.synchronize(dev)
   if dist is not None:
     dist.barrier()
@@ -170,6 +190,10 @@ def bench_train(args, rank, world, dev, dist):
     dist.barrier()
   elapsed = time.perf_counter() - t0
   assert torch.isfinite(loss.detach()).all()
+  ms = (C.c_double * 8)()
+  cnt = (C.c_int64 * 8)()
+  eng.lib.wg_profile_read(eng.handle, ms, cnt, 8)
+  eng.lib.wg_profile_enable(eng.handle, 0)
   if dist is not None:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -187,7 +211,8 @@ def bench_train(args, rank, world, dev, dist):
       "config": {"workload": f"configs[3]: {args.channels}ch train step, batch={B}/GPU x {S} samples, {F_} mel frames",
                  "parallelism": f"dp{world}, per-flow gradient all-reduce (RCCL) overlapped with backward"},
       "loss": float(loss.detach()),
-      "algorithmic_TFLOP_per_s": round(flops * args.steps / elapsed / 1e12, 1)}), flush=True)
+      "algorithmic_TFLOP_per_s": round(flops * args.steps / elapsed / 1e12, 1),
+      "roofline": train_roofline(hp, B, S, args.steps, ms, cnt)}), flush=True)
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()

@@ -131,7 +131,9 @@ double wg_macs_per_group_step(const wg_handle* h);
 
 /* Per-kernel device timing: when enabled, wg_infer brackets its kernels with hipEvents on `stream`;
  * wg_profile_read synchronises those events and returns accumulated milliseconds per kernel class.
- * classes: 0 = mel_pack, 1 = flow/start, 2 = wn_layer, 3 = memset. */
+ * classes: 0 = mel_pack, 1 = flow/start, 2 = wn_layer, 3 = memset; with n_classes = 8 also the training direction
+ * (wg_train_forward / wg_train_backward): 4 = fused layer forward, 5 = dgrad GEMMs, 6 = wgrad.  `on` = 1 times every class;
+ * a value > 1 is a bit mask of the classes to time (bit c = class c). */
 int wg_profile_enable(wg_handle* h, int32_t on);
 int wg_profile_read(wg_handle* h, double* ms_per_class, int64_t* launches_per_class, int32_t n_classes);
 

@@ -71,7 +71,7 @@ def _grad_worker(rank, world, port, q):
   assert len(red.buckets) >= 3
   red.reduce()
   if rank == 0:
-    q.put([p.grad.clone() for p in params])
+    q.put([p.grad.numpy().copy() for p in params])      # by value (see _dp_worker)
   dist.destroy_process_group()
 
 
@@ -96,7 +96,7 @@ def test_two_rank_gradient_allreduce_averages_buckets():
   for i in range(len(shapes)):
     a, b = want[0][i], want[1][i]
     ref = (a + (b if b is not None else torch.zeros_like(a))) / world
-    assert torch.allclose(got[i], ref, atol=1e-6), i
+    assert torch.allclose(torch.from_numpy(got[i]), ref, atol=1e-6), i
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -154,7 +154,7 @@ def _dp_worker(rank, world, port, q):
   flow_backward_schedule(_DP_GEOM["nf"], run_flow, bufs, dist.group.WORLD)
   dist.all_reduce = orig_all_reduce
   if rank == 0:
-    q.put((order, sent, bufs.flat.clone()))
+    q.put((order, sent, bufs.flat.numpy().copy()))     # by value: a tensor would travel as a shared-memory handle that dies with this process
   dist.destroy_process_group()
 
 
@@ -181,7 +181,7 @@ def test_two_rank_flow_schedule_equals_concatenated_batch_gradient():
   for k in range(nf):
     _fill_region(ref, k, X_all)
   ref.tail.copy_(_toy_flow_gradient(99, X_all, 8).repeat(ref.tail.numel() // 128 + 1)[:ref.tail.numel()])
-  assert torch.allclose(flat, ref.flat, rtol=1e-5, atol=1e-6)
+  assert torch.allclose(torch.from_numpy(flat), ref.flat, rtol=1e-5, atol=1e-6)
 
 
 def test_grad_buffers_layout():
@@ -265,7 +265,7 @@ def _train_worker(rank, world, port, n_files, tmp, q):
   gathered = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
   dist.all_gather(gathered, torch.tensor([len(losses)], dtype=torch.int64))
   if rank == 0:
-    q.put(([int(g) for g in gathered], training.get_all_checkpoint_iterations(ckp), w))
+    q.put(([int(g) for g in gathered], training.get_all_checkpoint_iterations(ckp), w.numpy().copy()))
   dist.destroy_process_group()
 
 

@@ -26,6 +26,11 @@ from waveglow_amd.model import WaveGlow  # noqa: E402
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 B, T = (16, 864)
+for f in sys.argv[2:]:
+  if f.startswith("B="):
+    B = int(f[2:])
+  if f.startswith("T="):
+    T = int(f[2:])
 hp = HParams(n_channels=C, n_flows=2, n_early_every=4)   # 2 flows are enough for phase shares
 # n_flows=2 leaves 8 channels; fine for timing
 sd = synthetic.make_state_dict(hp, 0)
@@ -37,6 +42,8 @@ with torch.no_grad():
   m.infer(mel, 0.6)
   eng = m._engine
   BN = 64 if C >= 512 else 128
+  if 32 * ((B * (T + 8) + 127) // 128) < torch.cuda.get_device_properties(0).multi_processor_count:
+    BN = 64                                                  # small workloads: the library picks 64-column tiles (api.cpp: run_wn)
   n_tiles = 32 * ((B * (T + 8) + 127) // 128 * 128) // BN   # 32 phases x (rows per phase block / BN), see RowGeom
   buf = torch.zeros(n_tiles * 8, dtype=torch.int64, device="cuda")
   eng.lib.wg_debug_set_stamp_buffer(eng.handle, buf.data_ptr())

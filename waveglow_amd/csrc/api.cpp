@@ -117,11 +117,12 @@ struct wg_handle {
   unsigned long long* dbg_stamps = nullptr;   // diagnostic builds only
   // profiling
   bool prof = false;
+  unsigned prof_mask = ~0u;
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_class;
   size_t ev_used = 0;
-  double prof_ms[4] = {0, 0, 0, 0};
-  int64_t prof_n[4] = {0, 0, 0, 0};
+  double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -215,6 +216,18 @@ int wg_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 const wg_config* wg_internal_config(const wg_handle* h) { return h ? &h->cfg : nullptr; }
 const int* wg_internal_flow_channels(const wg_handle* h) { return h ? h->c_k.data() : nullptr; }
 wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T) { return make_geom(h->cfg, B, L, T); }
+// one profiling event of class cls on stream s (a no-op unless wg_profile_enable is on); events come in begin/end pairs
+void wg_internal_prof_event(wg_handle* h, void* s, int cls) {
+  if (!h || !h->prof || !((h->prof_mask >> cls) & 1u)) return;
+  if (h->ev_used == h->ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    h->ev.push_back(e);
+    h->ev_class.push_back(0);
+  }
+  h->ev_class[h->ev_used] = cls;
+  hipEventRecord(h->ev[h->ev_used++], (hipStream_t)s);
+}
 
 extern "C" {
 
@@ -858,8 +871,9 @@ int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer) {
 int wg_profile_enable(wg_handle* h, int32_t on) {
   if (!h) return fail(WG_ERR_INVALID, "null handle");
   h->prof = on != 0;
+  h->prof_mask = on == 1 ? ~0u : (unsigned)on;      // on > 1: bit c set = class c is timed (fewer events per step)
   h->ev_used = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     h->prof_ms[i] = 0;
     h->prof_n[i] = 0;
   }
@@ -876,7 +890,7 @@ int wg_profile_read(wg_handle* h, double* ms, int64_t* n, int32_t n_classes) {
     h->prof_n[h->ev_class[i]] += 1;
   }
   h->ev_used = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (n_classes < 8 ? n_classes : 8); ++i) {
     ms[i] = h->prof_ms[i];
     n[i] = h->prof_n[i];
   }

@@ -295,20 +295,21 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     tile = start + idx;
   }
 
-  // bias of GEMM1 (pre-scaled: in_layer bias + cond_layer bias slice + W_cond . upsample bias), fp32 [2C], in LDS
-  float* const sBias = (float*)(sActs + BN * ACT_ROW);
-  if constexpr (!PLAIN) {
-    for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
-    if constexpr (HAS_RES)
-      for (int i = tid; i < C; i += NTHREADS) sBias[2 * C + i] = a.bias2[i];   // b_res, read by the pipelined epilogue
-  }
-
+  // (Measured and dropped: issuing the first tile's step-0 A fragments here, ahead of the bias loads, so that a cold
+  // launch pays one memory round trip instead of two -- no gain at batch 1, -0.6 % at config 1.)
   half8 q[4][MT];
   int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
   if (tile < tile_end) {
     const int p0 = tile / a.tiles_per_phase;
 #pragma unroll
     for (int i = 0; i < NG; ++i) stage_B_piece(p0, tile - p0 * a.tiles_per_phase, 0, 0, i);
+  }
+  // bias of GEMM1 (pre-scaled: in_layer bias + cond_layer bias slice + W_cond . upsample bias), fp32 [2C], in LDS
+  float* const sBias = (float*)(sActs + BN * ACT_ROW);
+  if constexpr (!PLAIN) {
+    for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
+    if constexpr (HAS_RES)
+      for (int i = tid; i < C; i += NTHREADS) sBias[2 * C + i] = a.bias2[i];   // b_res, read by the pipelined epilogue
   }
   __syncthreads();
 
@@ -342,6 +343,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         const bool ok = column_of(rr, p, b, t);
         mrow[i] = ok ? 3 + b * mel_rows_per_utt + 3 + (t >> 5) : 3;   // 3: rows 0..3 are zero, and mrow - j >= 0
       }
+    }
+    // Which of this lane's columns (one per N tile: row rr0 + nt*32 + ln) are real columns -- needed by the epilogue's
+    // plane stores; evaluated here, where the VALU idles behind the first loads, and carried through the K loop in one
+    // register (the epilogue phases are VALU-issue bound: ~8.5 cycles of phase time per instruction and wave).
+    unsigned vmask = 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int cb, ct;
+      vmask |= column_of(rr0 + nt * 32 + ln, p, cb, ct) ? (1u << nt) : 0u;
     }
     WG_STAMP(0);
     // ---- GEMM1 accumulators start from the bias
@@ -647,6 +657,17 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         xr[1] = xp[2];                                        // positions 16 + 8h .. +7    (k16 step 1)
       };
       load_xr(0);
+      // (Measured and dropped: storing a chunk's x_out rows one phase late, inside the next phase's slots, to keep the wait
+      // for the last MFMA out of the phase's tail -- the exec-masked store blocks in the middle of the slots cost 1 %.)
+      half8* const xo_base = (half8*)(a.x_out + ((size_t)(blk >> 1) * R + r0 + lno) * 64 + (blk & 1) * 32 + lho * 16);
+      auto store_xout_half = [&](const f32x16& d, int nt, int hf) {
+        if ((vmask >> nt) & 1u) {
+          half8 qv;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) qv[r] = (_Float16)d[8 * hf + r];
+          xo_base[(size_t)nt * 32 * 8 + hf] = qv;               // row + 32 nt: 32 rows x 64 halves = 256 half8
+        }
+      };
       __builtin_amdgcn_sched_barrier(0);
       // one phase; c is a compile-time constant (a plain unrolled loop over c left acc[..][c] dynamically indexed -- in
       // scratch -- in some instantiations)
@@ -700,8 +721,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         size_t save_off = 0;
         if constexpr (TR) {
           if (do_gate) {
-            int cb, ct;
-            save_ok = column_of(rr0 + c * 32 + lno, p, cb, ct);
+            save_ok = (vmask >> c) & 1u;
             save_off = ((size_t)(blk >> 1) * R + r0 + c * 32 + lno) * 64 + (blk & 1) * 32 + lho * 16;
           }
         }
@@ -750,19 +770,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         if (do_mm) {
           // x_out rows of chunk c-1 = fp16(x + b_res + W_res acts) for valid columns (model.py:130-132); every other row
           // of the plane stays zero: it is the convolution padding of other tiles
-          int cb, ct;
-          if (column_of(rr0 + ntm * 32 + lno, p, cb, ct)) {
-            half8 q0, q1;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-              q0[r] = (_Float16)d2[r];
-              q1[r] = (_Float16)d2[8 + r];
-            }
-            const size_t row = (size_t)(blk >> 1) * R + r0 + ntm * 32 + lno;
-            half8* xp = (half8*)(a.x_out + row * 64 + (blk & 1) * 32 + lho * 16);
-            xp[0] = q0;
-            xp[1] = q1;
-          }
+          store_xout_half(d2, ntm, 0);
+          store_xout_half(d2, ntm, 1);
         }
         if (do_gate) {
           // acts of chunk c complete in LDS for every wave before anyone's GEMM 2 reads them.  Raw barrier: the x_out

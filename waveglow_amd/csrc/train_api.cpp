@@ -16,6 +16,7 @@ int wg_set_error(int code, const char* msg);                              // api
 const wg_config* wg_internal_config(const wg_handle* h);                  // api.cpp
 const int* wg_internal_flow_channels(const wg_handle* h);                 // api.cpp
 wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T);    // api.cpp
+void wg_internal_prof_event(wg_handle* h, void* stream, int cls);         // api.cpp
 
 namespace {
 
@@ -32,6 +33,14 @@ namespace {
       fflush(stderr);                                                                        \
       if (_s != hipSuccess) return wg_set_error(WG_ERR_HIP, hipGetErrorString(_s));          \
     }                                                                                        \
+  } while (0)
+
+// per-class device timing of the training launches (wg_profile_enable / wg_profile_read, classes 4..7)
+#define TR_PROF(cls, stmt)                         \
+  do {                                             \
+    wg_internal_prof_event(h, (void*)s, cls);      \
+    stmt;                                          \
+    wg_internal_prof_event(h, (void*)s, cls);      \
   } while (0)
 
 bool dbg_sync() {
@@ -303,7 +312,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.save_t = w.T + (size_t)fl * w.plane_c;
         a.save_s = w.S + (size_t)fl * w.plane_c;
         a.save_a = Ai;
-        TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_layer_train(q, C, bn, s); }));
+        TR_PROF(4, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_layer_train(q, C, bn, s); })));
       }
     }
   }
@@ -425,7 +434,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.in0 = w.T + (size_t)fl * w.plane_c;
         a.in1 = w.S + (size_t)fl * w.plane_c;
         a.out0 = GPi;
-        TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, s); }));
+        TR_PROF(5, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, s); })));
       }
       {
         WgradArgs a;   // d W1 = d pre x [x taps | spect]^T, d b1
@@ -443,7 +452,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.out = w.slab;
         a.out_scale = 1.0f;
         a.bias_out = w.part;
-        TR_TRY(launch_wgrad(a, s));
+        TR_PROF(6, TR_TRY(launch_wgrad(a, s)));
         const size_t n = (size_t)2 * C * K1;
         TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + gofs(fl, n), s));
         TR_TRY(launch_slab_reduce(w.part, kPhases, 2 * C, 2 * C, inv, gr->db1 + gofs(fl, (size_t)2 * C), s));
@@ -465,7 +474,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.out = w.slab;
         a.out_scale = 1.0f;
         a.bias_out = w.part;
-        TR_TRY(launch_wgrad(a, s));
+        TR_PROF(6, TR_TRY(launch_wgrad(a, s)));
         const int ns = kPhases * small_split;
         const size_t slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
         if (gx) {
@@ -491,7 +500,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.n_cu = n_cu;
         a.in0 = gx;
         a.out0 = gx_next;
-        TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 2, bn, s); }));
+        TR_PROF(5, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 2, bn, s); })));
         gx = gx_next;
         gx_next = (gx == w.GX0) ? w.GX1 : w.GX0;
       }
