@@ -549,6 +549,71 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   }
 }
 
+struct SlabMultiArgs {
+  SlabSeg seg[kMaxSlabSegs];
+  unsigned first_block[kMaxSlabSegs + 1];    // blocks [first_block[i], first_block[i+1]) work on segment i
+  int n_segs;
+};
+__global__ void __launch_bounds__(256) slab_reduce_multi_kernel(const SlabMultiArgs a) {
+  __shared__ float4 part[4][64];
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSlabSegs; ++i)
+    if (i < a.n_segs && blockIdx.x >= a.first_block[i]) si = i;
+  const SlabSeg& g = a.seg[si];
+  const unsigned nb = a.first_block[si + 1] - a.first_block[si];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const size_t n4 = g.n >> 2;
+  for (size_t base = (size_t)(blockIdx.x - a.first_block[si]) * 64; base < n4; base += (size_t)nb * 64) {
+    const size_t i = base + tx;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (i < n4) {
+      int k = ty;
+      for (; k + 4 < g.n_slabs; k += 8) {
+        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
+        const float4 v = *(const float4*)(g.slabs + (size_t)(k + 4) * g.stride + 4 * i);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+      }
+      if (k < g.n_slabs) {
+        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+      }
+    }
+    part[ty][tx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (ty == 0 && i < n4) {
+      const float4 p0 = part[0][tx], p1 = part[1][tx], p2 = part[2][tx], p3 = part[3][tx];
+      float4 o;
+      o.x = ((p0.x + p1.x) + (p2.x + p3.x)) * g.scale;
+      o.y = ((p0.y + p1.y) + (p2.y + p3.y)) * g.scale;
+      o.z = ((p0.z + p1.z) + (p2.z + p3.z)) * g.scale;
+      o.w = ((p0.w + p1.w) + (p2.w + p3.w)) * g.scale;
+      *(float4*)(g.out + 4 * i) = o;
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t s) {
+  if (n_segs < 1 || n_segs > kMaxSlabSegs) return hipErrorInvalidValue;
+  SlabMultiArgs a;
+  a.n_segs = n_segs;
+  unsigned total = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    if ((segs[i].n & 3) || (segs[i].stride & 3) || !segs[i].slabs || !segs[i].out) return hipErrorInvalidValue;
+    a.seg[i] = segs[i];
+    a.first_block[i] = total;
+    size_t blocks = (segs[i].n / 4 + 63) / 64;     // same arithmetic (and summation order) as slab_reduce_kernel
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    total += (unsigned)blocks;
+  }
+  for (int i = n_segs; i <= kMaxSlabSegs; ++i) a.first_block[i] = total;
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(total), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
                               hipStream_t s) {
   if ((n & 3) || (stride & 3)) return hipErrorInvalidValue;

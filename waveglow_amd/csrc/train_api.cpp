@@ -61,8 +61,8 @@ struct TrainWs {
   _Float16 *GX0, *GX1, *GO, *SP, *MELP, *GSP;
   float *Zpost, *OUT;           // [n_flows][B*L*8]
   float *GZ;                    // [B*L*8]
-  float *slab;                  // wgrad phase slabs
-  float *part;                  // column-sum / row-kernel partials
+  float *slab, *slab2;          // wgrad phase slabs (dW1 | dW2 + end x skip: both alive until the layer's one reduction launch)
+  float *part, *part2;          // column-sum / row-kernel partials
   size_t plane_c;               // elements of one C-channel plane set
   size_t rows8;                 // B*L*8
   size_t zero_bytes;            // prefix that `fresh` clears (all planes)
@@ -94,10 +94,12 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.GZ = (float*)take(w.rows8 * 4);
   const size_t K1 = 3 * (size_t)C + M8;
   w.slab = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
+  w.slab2 = (float*)take((size_t)kPhases * 4 * (C + 64) * C * 4);          // row_split 4: [128 slabs][(C/64 + 1) * 64][C]
   size_t part = (size_t)kPhases * 4 * max_sz(2 * (size_t)C, (size_t)M8);     // bias partials: [slabs][rows]
   part = max_sz(part, (size_t)flow_bwd_workgroups(g) * 64);
   part = max_sz(part, (size_t)start_wgrad_workgroups(g) * 5 * C);
   w.part = (float*)take(part * 4);
+  w.part2 = (float*)take((size_t)kPhases * 4 * (C + 64) * 4);
   w.bytes = off;
   return w;
 }
@@ -453,9 +455,6 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.out_scale = 1.0f;
         a.bias_out = w.part;
         TR_PROF(6, TR_TRY(launch_wgrad(a, s)));
-        const size_t n = (size_t)2 * C * K1;
-        TR_TRY(launch_slab_reduce(w.slab, kPhases, n, n, inv, gr->dw1 + gofs(fl, n), s));
-        TR_TRY(launch_slab_reduce(w.part, kPhases, 2 * C, 2 * C, inv, gr->db1 + gofs(fl, (size_t)2 * C), s));
       }
       {
         // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
@@ -471,19 +470,30 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.k_chunks = cc;
         a.g = g;
         a.row_split = small_split;
-        a.out = w.slab;
+        a.out = w.slab2;
         a.out_scale = 1.0f;
-        a.bias_out = w.part;
+        a.bias_out = w.part2;
         TR_PROF(6, TR_TRY(launch_wgrad(a, s)));
+        // ONE reduction launch for everything the layer's two weight-gradient launches left in their slabs
         const int ns = kPhases * small_split;
-        const size_t slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
+        const size_t n1 = (size_t)2 * C * K1, slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
+        SlabSeg seg[kMaxSlabSegs];
+        int nseg = 0;
+        auto add = [&](const float* slabs, int n_slabs, size_t stride, size_t n, float* out) {
+          seg[nseg].slabs = slabs; seg[nseg].out = out; seg[nseg].stride = stride; seg[nseg].n = n;
+          seg[nseg].n_slabs = n_slabs; seg[nseg].scale = inv;
+          ++nseg;
+        };
+        add(w.slab, kPhases, n1, n1, gr->dw1 + gofs(fl, n1));
+        add(w.part, kPhases, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C));
         if (gx) {
-          TR_TRY(launch_slab_reduce(w.slab, ns, slab_n, (size_t)C * C, inv, gr->dw2 + gofs(fl, (size_t)C * C), s));
-          TR_TRY(launch_slab_reduce(w.part, ns, bias_n, C, inv, gr->db2 + gofs(fl, (size_t)C), s));
+          add(w.slab2, ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C));
+          add(w.part2, ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C));
         }
-        TR_TRY(launch_slab_reduce(w.slab + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, inv, gr->dwes + gofs(fl, (size_t)8 * C), s));
+        add(w.slab2 + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C));
         // d out_init = sum over columns of (d b | d log_s), once per flow
-        if (i == 0) TR_TRY(launch_slab_reduce(w.part + (size_t)gc * 64, ns, bias_n, 8, inv, gr->dout_init[k], s));
+        if (i == 0) add(w.part2 + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k]);
+        TR_TRY(launch_slab_reduce_multi(seg, nseg, s));
       }
       {
         // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)   (wn_layer_kernel MODE 2: taps at +d, 0, -d)

@@ -111,6 +111,18 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
                               hipStream_t s);
+// the same reduction for up to kMaxSlabSegs independent (slabs, out) pairs in ONE launch: a layer's weight-gradient
+// launches leave six small-to-large slab sets behind, and six launches of a few microseconds each cost more in launch
+// gaps than in traffic
+constexpr int kMaxSlabSegs = 6;
+struct SlabSeg {
+  const float* slabs;
+  float* out;
+  size_t stride, n;      // n % 4 == 0, stride % 4 == 0
+  int n_slabs;
+  float scale;
+};
+hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t s);
 hipError_t launch_mel_plane(const void* mel, int io_f16, int M, const RowGeom& g, _Float16* melp, hipStream_t s);
 hipError_t launch_flow_bwd_pre(const FlowBwdArgs& a, hipStream_t s);
 hipError_t launch_flow_bwd_post(const FlowBwdArgs& a, hipStream_t s);

@@ -222,20 +222,24 @@ class _Weights:
     # forward operands: natural rows, the WN-layer kernel's fragment order
     self.a1, self.a1c, self.b1, self.a2, self.es = wn_forward_fragments(nat[0], nat[1], nat[2], nat[4], pm, NW)
     self.b2 = nat[3].float().contiguous()
-    # backward operands: (pos,pos) matrices in the plane GEMM's fragment order
-    w1, b1, w2, b2, wes, wup, bup, start5, out_init, w1x1 = to_pos_order(nat, pm)
-    FL = w1.shape[0]
-    r32, c2p = pm.r32, pm.c2p
-    w1h, w2h = w1.half(), w2.half()
-    self.bup = bup.float()
+    # backward operands of the plane GEMM: (pos,pos) matrices in its fragment order.  Only what that kernel still
+    # multiplies is permuted -- the cond_layer slice (d spect GEMM) and the upsample filter -- not the whole of w1
+    # (two gather passes over 277 MB at 256 channels)
+    FL = nat[0].shape[0]
+    c2p = pm.c2p
+    w1h = nat[0].half()                                   # one fp32 -> fp16 pass; every gather below moves fp16
+    w1c = w1h[:, :, 3 * Cc:].index_select(1, pm.c2).index_select(2, pm.m8)               # [FL, 2C pos, M8 pos]
+    wup = nat[5].index_select(1, pm.m8)
+    self.bup = nat[6].index_select(0, pm.m8).float()
+    start5, out_init, w1x1 = nat[7].index_select(2, pm.c), nat[8], nat[9]
     # dgrad GEMMs (WN-layer kernel, plain rows): rows natural, K in the position order of the gradient planes
-    n_w1, n_w2, n_wes = nat[0], nat[2], nat[4]
+    n_w1, n_w2, n_wes = w1h, nat[2], nat[4]
     wat_m = torch.cat([n_w2.transpose(1, 2).index_select(2, pm.c),                          # [FL, C acts, C d-x positions]
                        torch.nn.functional.pad(n_wes.half().float(), (0, 0, 0, 56)).transpose(1, 2)], 2)   # | 64 d-out channels
     self.wat = plain_fragments(wat_m.half(), NW)
     self.wbt = plain_fragments(torch.cat([n_w1[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2).index_select(2, pm.c2)
-                                          for t in range(3)], 2).half(), NW)
-    self.wct = to_fragments(w1h[:, :, 3 * Cc:].permute(2, 0, 1).reshape(-1, FL * 2 * Cc), c2p)
+                                          for t in range(3)], 2), NW)
+    self.wct = to_fragments(w1c.permute(2, 0, 1).reshape(-1, FL * 2 * Cc), c2p)
     self.wup = to_fragments(wup.half(), c2p)
     self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
     self.bstart = [start5[k, 4].contiguous().float() for k in range(nf)]
