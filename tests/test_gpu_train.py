@@ -119,6 +119,22 @@ def test_train_step_c256_two_utterances():
   _check(grads, g_ref, "c256")
 
 
+@pytest.mark.parametrize("force_bn", ["128", "64"])
+def test_train_step_both_layer_tile_widths(force_bn, monkeypatch):
+  """The fused layer forward and the two dgrad GEMMs run on the WN-layer kernel, whose tile width (128 or 64 columns)
+  is chosen by workload size: small test shapes would only ever see 64.  Both widths, 256 channels (8 waves, the
+  pipelined epilogue with saved activations) and 64 channels (2 waves), against the oracle."""
+  from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_FORCE_BN", force_bn)
+  for over, B, T, seed in ((dict(n_layers=3, n_flows=2, n_early_every=1, n_early_size=2), 3, 11, 4),
+                           (dict(n_channels=64, n_layers=8, n_flows=4, n_early_every=2), 5, 9, 6)):
+    hp, sd, mel, wav = _setup(over, B, T, seed, crop=56)
+    loss, y, grads = _gpu_step(hp, sd, mel, wav)
+    loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+    assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+    _check(grads, g_ref, f"bn{force_bn}/c{hp.n_channels}")
+
+
 @pytest.mark.parametrize("ct", ["2", "3", "4", "6"])
 def test_train_step_every_tile_width(ct, monkeypatch):
   """Rp = 384 rows per phase divides by 64, 96, 128 and 192: every tile width of the plane GEMM gives the same

@@ -338,3 +338,53 @@ def test_wav_helpers_match_reference_fixture(tmp_path):
       got = A.convert_wav(x.copy(), np.float32)
       assert got.dtype == np.float32 and np.array_equal(got, fx[f"{name}/as_float32"]), name
   assert n_assert >= 1
+
+
+def test_wn_kernel_fragment_orders():
+  """The A-fragment orders of the WN-layer kernel as the training direction packs them on the device
+  (waveglow_amd/train.py: wn_forward_fragments, plain_fragments; include/waveglow_amd.h: wg_train_weights a1 / a1c / a2 /
+  es / wat / wbt): every element of the packed tensors against the documented index map, on matrices whose entries encode
+  their own (row, column)."""
+  import torch
+  from waveglow_amd.train import K_SIGM_SCALE, K_TANH_SCALE, _perms, plain_fragments, pos_perm, wn_forward_fragments
+  Cc, M8, NW, FL = 64, 128, 2, 2
+  MB = Cc // (32 * NW)
+  pm = _perms(Cc, M8, torch.device("cpu"))
+  K1 = 3 * Cc + M8
+  rows = torch.arange(2 * Cc, dtype=torch.float32)
+  cols = torch.arange(K1, dtype=torch.float32)
+  w1 = (rows[:, None] * 0.001 + cols[None, :] * 1e-6 + 0.25).expand(FL, -1, -1).clone()
+  w1[1] += 0.125
+  b1 = torch.arange(FL * 2 * Cc, dtype=torch.float32).view(FL, 2 * Cc) * 0.01
+  w2 = (torch.arange(Cc, dtype=torch.float32)[:, None] * 0.01 + torch.arange(Cc, dtype=torch.float32)[None, :] * 1e-4).expand(FL, -1, -1).clone()
+  wes = (torch.arange(8, dtype=torch.float32)[:, None] * 0.1 + torch.arange(Cc, dtype=torch.float32)[None, :] * 1e-3).expand(FL, -1, -1).clone()
+  a1, a1c, b1s, a2, es = wn_forward_fragments(w1, b1, w2, wes, pm, NW)
+  nK = K1 // 64
+  a = torch.cat([a1, a1c], 1).view(FL, nK, 2, NW, 2 * MB, 2, 64, 8)
+  kpos = pm.k1                                            # natural K index stored at K position P
+  scale = lambda m: K_TANH_SCALE if m < Cc else K_SIGM_SCALE
+  for (f, ks, u1, w, mt, k2, lane, j) in [(0, 0, 0, 0, 0, 0, 0, 0), (1, 3, 1, 1, 1, 1, 37, 5), (0, nK - 1, 1, 0, 1, 0, 63, 7), (1, 1, 0, 1, 0, 1, 31, 2)]:
+    r, hh = lane & 31, lane >> 5
+    m = (0 if mt < MB else Cc) + 32 * (w * MB + (mt % MB)) + r
+    P = 64 * ks + 32 * u1 + 16 * k2 + 8 * hh + j
+    want = (w1[f, m, kpos[P]] * scale(m)).half()
+    assert a[f, ks, u1, w, mt, k2, lane, j] == want, (f, ks, u1, w, mt, k2, lane, j)
+  assert torch.allclose(b1s[1, 5], b1[1, 5] * K_TANH_SCALE) and torch.allclose(b1s[0, Cc + 3], b1[0, Cc + 3] * K_SIGM_SCALE)
+  a2v = a2.view(FL, NW, MB, Cc // 16, 64, 8)
+  pc = pos_perm(Cc)
+  for (f, w, mb, k16, lane, j) in [(0, 0, 0, 0, 0, 0), (1, 1, 0, 3, 45, 6)]:
+    r, hh = lane & 31, lane >> 5
+    assert a2v[f, w, mb, k16, lane, j] == w2[f, 32 * (w * MB + mb) + r, pc[16 * k16 + 8 * hh + j]].half()
+  esv = es.view(FL, Cc // 32, 64, 8)
+  for (f, s_, lane, j) in [(0, 0, 3, 1), (1, 1, 9 + 16 * 2, 4)]:
+    row, l4 = lane & 15, lane >> 4
+    full = wes[f, row & 7, pc[32 * s_ + 8 * l4 + j]]
+    hi = full.half()
+    want = hi if row < 8 else (full - hi.float()).half()
+    assert esv[f, s_, lane, j] == want
+  # plain row blocks (dgrad GEMMs)
+  mat = (torch.arange(Cc, dtype=torch.float32)[:, None] * 0.01 + torch.arange(128, dtype=torch.float32)[None, :] * 1e-4).expand(FL, -1, -1).half()
+  pf = plain_fragments(mat, NW).view(FL, 2, 2, NW, MB, 2, 64, 8)
+  for (f, ks, u1, w, mb, k2, lane, j) in [(0, 0, 0, 0, 0, 0, 0, 0), (1, 1, 1, 1, 0, 1, 50, 3)]:
+    r, hh = lane & 31, lane >> 5
+    assert pf[f, ks, u1, w, mb, k2, lane, j] == mat[f, 32 * (w * MB + mb) + r, 64 * ks + 32 * u1 + 16 * k2 + 8 * hh + j]
