@@ -1,0 +1,22 @@
+#!/bin/bash
+# Interleaved training bench of the in-tree library (A) and several -D variants on ONE box:
+#   tools/ab_train.sh "<flags1>" "<flags2>" ...     prints ms/step and the weight-gradient kernel's ms/step per run
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $ROOT/gpurun_out
+i=0
+for F in "$@"; do
+  i=$((i+1))
+  (cd $ROOT/waveglow_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value $F -o $ROOT/gpurun_out/lib_v$i.so kernels.hip stft.hip train.hip api.cpp stft_api.cpp train_api.cpp) || exit 1
+done
+for round in 1 2; do
+  for v in $(seq 0 $i); do
+    if [ $v = 0 ]; then unset WAVEGLOW_AMD_LIB; name="A (in-tree)"; else export WAVEGLOW_AMD_LIB=$ROOT/gpurun_out/lib_v$v.so; name="V$v"; fi
+    timeout -k 10 300 python $ROOT/bench.py --workload train --no-cpu-baseline --steps 4 --warmup 2 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+  if l.startswith('{'):
+    d = json.loads(l); r = d['roofline']
+    print('$name round $round: %.3f ms/step  wgrad %.3f ms/step' % (d['ms_per_step'], r['kernel_ms_per_step']['wgrad']))
+"
+  done
+done

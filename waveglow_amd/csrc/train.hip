@@ -31,6 +31,14 @@ __device__ __forceinline__ size_t shifted_row(const RowGeom& g, int p, int dt) {
   return (size_t)((long long)kRowPad + (long long)(pp & 31) * g.Rp + (pp >> 5));
 }
 
+// XCD-aware workgroup order (cdna_hip_programming.md T1, bijective form): blocks are dealt round-robin over the 8 XCDs,
+// each with its own L2, so the blocks that share an operand tile are given CONSECUTIVE logical ids on ONE XCD: block
+// `bid` of `nwg` becomes logical workgroup (its XCD label's contiguous range) + (its turn on that XCD).  Speed only.
+__device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nwg) {
+  const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, int& b, int& t) {
   b = rr / g.Fp;
   const int f = rr - b * g.Fp - g.Gf;
@@ -72,12 +80,15 @@ plane_gemm_kernel(const PGemmArgs a) {
   const int r = lane & 31, h = lane >> 5;
   const RowGeom& g = a.g;
   const int tpp = g.Rp / BN;
-  const int tile = blockIdx.x;
+  // the row groups of one column tile (same B tile, streamed over the whole K) are consecutive workgroups of one XCD:
+  // the tile comes out of HBM once instead of once per row group (the K = 49152 cond_layer dgrad has five)
+  const unsigned wgid = xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int by = (int)(wgid % gridDim.y), tile = (int)(wgid / gridDim.y);
   const int p = tile / tpp, r0 = (tile - p * tpp) * BN;
   // A residual launch can carry the folded end x skip GEMM as one extra row group (same B operand: the acts planes;
   // 32-row matrix a.A_es, epilogue of EPI_ES) instead of a launch of its own.
-  const bool es_group = (EPI == EPI_RES) && a.A_es != nullptr && blockIdx.y == gridDim.y - 1;
-  const int blk = es_group ? w : blockIdx.y * PG_WAVES + w;
+  const bool es_group = (EPI == EPI_RES) && a.A_es != nullptr && by == (int)gridDim.y - 1;
+  const int blk = es_group ? w : by * PG_WAVES + w;
   const bool active = blk * 32 < (es_group ? 32 : a.M);
   const size_t R64 = (size_t)g.R * 64;
 
@@ -271,7 +282,7 @@ plane_gemm_kernel(const PGemmArgs a) {
   }
   if (EPI == EPI_GATE && a.stamps && tid == 0) {
     tstamp[3] = __builtin_amdgcn_s_memtime();
-    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    unsigned long long* o = a.stamps + ((size_t)by * gridDim.x + tile) * 4;
     o[0] = tstamp[0]; o[1] = tstamp[1]; o[2] = tstamp[2]; o[3] = tstamp[3];
   }
 }
@@ -346,48 +357,101 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
 // quadrant as 4 x 4 MFMA tiles of 16 x 16.  Both operands are [row][channel] planes and the contraction runs over
 // ROWS, so an MFMA fragment (8 k = rows, one channel per lane) is a column of the LDS tile: fetched with
 // ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4-row x 16-column block
-// (cdna_hip_programming.md T10).
-// Register-staged tiles two steps ahead, branch-free loop (see plane_gemm_kernel).  Chunks past the end of an operand
-// are clamped to its last chunk: their products are computed and never stored.
-// Guard / invalid rows of G are zero by construction (every producer writes zeros there), so no row masking.
+// (cdna_hip_programming.md T10).  Chunks past the end of an operand are clamped to its last chunk: their products are
+// computed and never stored.  Guard / invalid rows of G are zero by construction (every producer writes zeros there),
+// so no row masking.
+//
+// v_mfma_f32_16x16x32_f16: one MFMA spans the 32 rows of a step (same-box A/B against a 32x32x16 version: 10 % faster
+// at equal MFMA cycles -- the chip holds a higher clock with the 16x16 shape).  Lane group g reads rows 4g..4g+3 and
+// 16+4g..16+4g+3, so a 32-lane half touches 8 consecutive rows x 32 B.
+//
+// Staging: LDS-DMA (global_load_lds_dwordx4) into a three-stage ring, two steps ahead (round 1 staged the tiles
+// global -> VGPR -> ds_write: 24 more registers, a commit phase before every barrier, one workgroup per CU; this form
+// fits 128 registers = two workgroups per CU).  A DMA instruction writes 64 consecutive 16-byte slots, so the LDS
+// tile cannot be padded; it is [unit = chunk x 8-row block][8 rows][128 B] with the 32-byte column blocks of row r
+// XOR-ed with (r >> 1) & 3 (applied on the SOURCE side: lane -> which 16 bytes of its row it fetches): the 8 rows x
+// 32 B a 32-lane half of ds_read_b64_tr_b16 touches then fall on 8 different 32-byte bank groups.  Per step and
+// thread 3 DMAs (units w, 8 + w of G; unit w of X), all hand-counted (vmcnt): see glds16 in kernels.hip.
+//
+// One launch carries up to TWO jobs (WgradPair): a layer's d W1 (704 workgroups of 72 steps at config 4: 1.4 rounds of
+// the 512 resident workgroups) and its d W2 / end x skip (512 workgroups of 18 steps), whose workgroups fill the
+// slots the first job's last round leaves idle.  Within a job, the workgroups of one slab (they share its G and X
+// rows) are consecutive on one XCD (xcd_order): a step's rows come out of HBM once per slab, not once per XCD.
 // =============================================================================================
-// v_mfma_f32_16x16x32_f16 (one MFMA spans the 32 rows of a step; same-box A/B against the 32x32x16 version of this
-// kernel: 10 % faster at equal MFMA cycles -- the chip holds a higher clock with the 16x16 shape).  Lane group g reads
-// rows 4g..4g+3 and 16+4g..16+4g+3, so a 32-lane half touches 8 consecutive rows x 32 B: row strides of 32 B
-// (mod 256 B) are conflict-free.
-constexpr int WG_GS = 272;      // LDS row stride of the G tile in halves (4 chunks + 32 B)
-constexpr int WG_XS = 144;      // ... of the X tile (2 chunks + 32 B)
-constexpr int WG_STEP = 32;     // rows per step (64-row steps -- 16 MFMAs between barriers, 112 KB of LDS -- measured 10 % slower)
-constexpr int WG_LDS_BYTES = 2 * WG_STEP * (WG_GS + WG_XS) * 2;   // 53 248 B, dynamic
+constexpr int WG_STEP = 32;     // rows per step (64-row steps -- 16 MFMAs between barriers -- measured 10 % slower)
+constexpr int WD_STAGES = 3;
+constexpr int WD_STAGE_BYTES = 24 * 1024;                 // 16 units of G (4 chunks x 32 rows x 128 B) + 8 of X
+constexpr int WD_LDS_BYTES = WD_STAGES * WD_STAGE_BYTES;  // 72 KB: two workgroups per CU
 
-__global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 wg_smem[];
-  _Float16* const sG[2] = {wg_smem, wg_smem + WG_STEP * WG_GS};
-  _Float16* const sX[2] = {wg_smem + 2 * WG_STEP * WG_GS, wg_smem + 2 * WG_STEP * WG_GS + WG_STEP * WG_XS};
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+namespace {
+__device__ __forceinline__ void tr_glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+template <int N> __device__ __forceinline__ void tr_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+struct WgradPair {
+  WgradArgs job[2];
+  unsigned nwg[2];        // workgroups of each job (the second may be 0)
+};
+inline unsigned wgrad_workgroups(const WgradArgs& a) {
+  return (unsigned)((a.m_chunks + 3) / 4) * (unsigned)((a.k_chunks + 1) / 2) * (unsigned)(kPhases * a.row_split);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) wgrad_kernel(const WgradPair pr) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 wg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wk = w & 1;
+  const bool second = blockIdx.x >= pr.nwg[0];
+  const WgradArgs& a = second ? pr.job[1] : pr.job[0];
   const RowGeom& g = a.g;
-  const int slab = blockIdx.z;
+  const unsigned gx = (unsigned)(a.m_chunks + 3) / 4, gy = (unsigned)(a.k_chunks + 1) / 2;
+  const unsigned wgid = xcd_order(second ? blockIdx.x - pr.nwg[0] : blockIdx.x, second ? pr.nwg[1] : pr.nwg[0]);
+  const int bx = (int)(wgid % gx), by = (int)((wgid / gx) % gy);
+  const int slab = (int)(wgid / (gx * gy));
   const int p = slab / a.row_split, rs = slab - p * a.row_split;
   const int rows_per = g.Rp / a.row_split;
-  const int mc0 = blockIdx.x * 4, kc0 = blockIdx.y * 2;
+  const int mc0 = bx * 4, kc0 = by * 2;
   const size_t R64 = (size_t)g.R * 64;
 
-  // staging.  G: pieces tid + 512 q (q < WG_STEP/16): row = (tid >> 5) + 16 q, chunk e = (tid >> 3) & 3, piece = tid & 7
-  //           X: pieces tid + 512 q (q < WG_STEP/32): row = (tid >> 4) + 32 q, chunk e = (tid >> 3) & 1, piece = tid & 7
-  const int grow = tid >> 5, ge = (tid >> 3) & 3, xrow = tid >> 4, xe = (tid >> 3) & 1, spc = tid & 7;
-  const int gch = (mc0 + ge < a.m_chunks) ? mc0 + ge : a.m_chunks - 1;
-  const _Float16* gbase = (a.G_last && gch == a.m_chunks - 1) ? a.G_last : a.G + (size_t)gch * R64;
-  const _Float16* gsrc = gbase + ((size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + grow) * 64 + spc * 8;
-  const _Float16* xsrc;
+  // DMA units of this wave: G chunk (w >> 2) and 2 + (w >> 2), X chunk (w >> 2); 8-row block rb = w & 3 of the step
+  const int rb = w & 3;
+  auto g_chunk_base = [&](int e) -> const _Float16* {
+    const int gch = (mc0 + e < a.m_chunks) ? mc0 + e : a.m_chunks - 1;
+    return (a.G_last && gch == a.m_chunks - 1) ? a.G_last : a.G + (size_t)gch * R64;
+  };
+  const size_t grow0 = (size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + 8 * rb;
+  const char* src0 = uniform_ptr(g_chunk_base(w >> 2) + grow0 * 64);
+  const char* src1 = uniform_ptr(g_chunk_base(2 + (w >> 2)) + grow0 * 64);
+  const char* src2;
   {
-    int c = (kc0 + xe < a.k_chunks) ? kc0 + xe : a.k_chunks - 1;
+    int c = (kc0 + (w >> 2) < a.k_chunks) ? kc0 + (w >> 2) : a.k_chunks - 1;
     int i = 0;
     while (c >= a.run[i].n_chunks) { c -= a.run[i].n_chunks; ++i; }
-    xsrc = a.run[i].base + (size_t)c * R64 + (shifted_row(g, p, a.run[i].dt) + (size_t)rs * rows_per + xrow) * 64 + spc * 8;
+    src2 = uniform_ptr(a.run[i].base + (size_t)c * R64 + (shifted_row(g, p, a.run[i].dt) + (size_t)rs * rows_per + 8 * rb) * 64);
   }
-  const int lds_g = grow * WG_GS + ge * 64 + spc * 8;
-  const int lds_x = xrow * WG_XS + xe * 64 + spc * 8;
+  // lane -> (row lr of the 8-row block, 16-byte slot): fetches piece slot ^ (key << 1) of its row, key = (row >> 1) & 3
+  const int lr = lane >> 3;
+  const unsigned voff = (unsigned)(lr * 128 + (((lane & 7) ^ (((lr >> 1) & 3) << 1)) << 4));
+  const unsigned smem_addr = (unsigned)(size_t)((__attribute__((address_space(3))) void*)wg_smem);
+  const unsigned lds_u = __builtin_amdgcn_readfirstlane(smem_addr + (unsigned)w * 1024u);   // unit w of stage 0
+
+  auto issue = [&](int st) {    // the three DMAs of step st
+    const unsigned base = lds_u + (unsigned)(st % WD_STAGES) * WD_STAGE_BYTES;
+    const size_t ro = (size_t)st * WG_STEP * 128;
+    tr_glds16(src0 + ro, voff, base);
+    tr_glds16(src1 + ro, voff, base + 8 * 1024);
+    tr_glds16(src2 + ro, voff, base + 16 * 1024);
+  };
 
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v acc[4][4], accb[4];
@@ -400,73 +464,60 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) accb[i][j] = 0.0f;
   }
-  const bool do_bias = a.bias_out != nullptr && blockIdx.y == 0 && wk == 0;
+  const bool do_bias = a.bias_out != nullptr && by == 0 && wk == 0;
   half8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
-  constexpr int GQ = WG_STEP / 16, XQ = WG_STEP / 32;
-  half8 gst[2][GQ], xst[2][XQ];
-  auto fetch = [&](int par, int st) {
-    const size_t ro = (size_t)st * WG_STEP * 64;
-#pragma unroll
-    for (int q = 0; q < GQ; ++q) gst[par][q] = *(const half8*)(gsrc + ro + (size_t)q * 16 * 64);
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) xst[par][q] = *(const half8*)(xsrc + ro + (size_t)q * 32 * 64);
-  };
-  auto commit = [&](int buf, int par) {
-#pragma unroll
-    for (int q = 0; q < GQ; ++q) *(half8*)&sG[buf][lds_g + q * 16 * WG_GS] = gst[par][q];
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) *(half8*)&sX[buf][lds_x + q * 32 * WG_XS] = xst[par][q];
-  };
 
-  // transposing fragment read for the 16x16x32 MFMA: operand lane (r = lane & 15, g = lane >> 4) needs 8 k values
-  // of channel r; k = 8g + j is tile row 4g + j (j < 4) / 16 + 4g + j - 4 (j >= 4) -- both operands use the same map.
+  // transposing fragment reads: operand lane (u = lane & 15, g16 = lane >> 4) needs 8 k values of channel u of a
+  // 16-channel block; k = 8 g16 + j is tile row 4 g16 + j (j < 4) / 16 + 4 g16 + j - 4 (j >= 4) -- both operands use the
+  // same map.  The lane's read starts at tile row 4 g16 + (u >> 2), halves 4 (u & 3) of the block, which sits at
+  // block position i ^ key(row); the second read is 16 rows further (same key).
   const int g16 = lane >> 4, u = lane & 15;
-  const int tr_row = 4 * g16 + (u >> 2), tr_col = 4 * (u & 3);
-  auto frag = [&](const _Float16* tile, int stride, int col0) -> half8 {
-    const _Float16* q0 = tile + tr_row * stride + tr_col + col0;
+  const int tr_row = 4 * g16 + (u >> 2);
+  const int tr_key = (tr_row >> 1) & 3;
+  int tr_off[4];   // halves, inside a [32 rows][64] chunk tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tr_off[i] = tr_row * 64 + ((i ^ tr_key) << 4) + 4 * (u & 3);
+  auto frag = [&](const _Float16* chunk_tile, int i) -> half8 {
+    const _Float16* q0 = chunk_tile + tr_off[i];
     const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)q0);
-    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 16 * stride));
+    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 16 * 64));
     const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
     return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  static_assert(WG_STEP == 32, "one 16x16x32 MFMA spans the rows of a step");
 
-  const int n_steps = rows_per / WG_STEP, last = n_steps - 1;
-  fetch(0, 0);
-  fetch(1, last < 1 ? last : 1);
-  commit(0, 0);
-  __syncthreads();
-  auto body = [&](auto PAR, int st) {
-    constexpr int par = decltype(PAR)::value;
-    fetch(par, st + 2 < last ? st + 2 : last);
+  const int n_steps = rows_per / WG_STEP;
+  issue(0);
+  if (n_steps > 1) issue(1);
+  for (int st = 0; st < n_steps; ++st) {
+    if (st + 1 < n_steps) tr_wait_vm<3>(); else tr_wait_vm<0>();      // this thread's pieces of step st have landed
+    __syncthreads();                                                  // everyone's have; stage (st + 2) % 3 is free
+    if (st + 2 < n_steps) issue(st + 2);
     __builtin_amdgcn_sched_barrier(0);
-    half8 af[4], bf[4];
+    const _Float16* stage = wg_smem + (size_t)(st % WD_STAGES) * (WD_STAGE_BYTES / 2);
+    const _Float16* gt = stage + wm * 2048;               // G chunk wm: 4 units of 512 halves
+    const _Float16* xt = stage + (4 + wk) * 2048;         // X chunk wk
+    // X fragments one MFMA group ahead (4 + 2 fragments live instead of 8: the kernel has to fit 128 registers for
+    // two workgroups per CU, whose waves cover each other's LDS latency)
+    half8 af[4], bf[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i] = frag(sG[par], WG_GS, wm * 64 + 16 * i);
-      bf[i] = frag(sX[par], WG_XS, wk * 64 + 16 * i);
+    for (int i = 0; i < 4; ++i) af[i] = frag(gt, i);
+    bf[0] = frag(xt, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < 3) bf[(k + 1) & 1] = frag(xt, k + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[k & 1], acc[i][k], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[k], acc[i][k], 0, 0, 0);
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    commit(par ^ 1, par ^ 1);
-    __syncthreads();
-  };
-  int st = 0;
-  for (; st + 1 < n_steps; st += 2) {
-    body(std::integral_constant<int, 0>{}, st);
-    body(std::integral_constant<int, 1>{}, st + 1);
   }
-  if (st < n_steps) body(std::integral_constant<int, 0>{}, st);
 
   // D: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int Mtot = a.m_chunks * 64, Ktot = a.k_chunks * 64;
@@ -494,19 +545,33 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradArgs a) {
   }
 }
 
-hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+namespace {
+hipError_t check_wgrad(const WgradArgs& a) {
   if (a.n_runs < 1 || a.n_runs > kMaxRuns || a.row_split < 1 || a.g.Rp % (a.row_split * WG_STEP)) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks;
   if (k != a.k_chunks || a.m_chunks < 1) return hipErrorInvalidValue;
+  return hipSuccess;
+}
+}  // namespace
+
+// `b` (optional) rides in the same launch, behind `a`: put the job with the longer workgroups first
+hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s) {
+  hipError_t e = check_wgrad(a);
+  if (e == hipSuccess && b) e = check_wgrad(*b);
+  if (e != hipSuccess) return e;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES);
+    e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  dim3 grid((a.m_chunks + 3) / 4, (a.k_chunks + 1) / 2, kPhases * a.row_split);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(512), WG_LDS_BYTES, s, a);
+  WgradPair pr;
+  pr.job[0] = a;
+  pr.job[1] = b ? *b : a;
+  pr.nwg[0] = wgrad_workgroups(a);
+  pr.nwg[1] = b ? wgrad_workgroups(*b) : 0u;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(pr.nwg[0] + pr.nwg[1]), dim3(512), WD_LDS_BYTES, s, pr);
   return hipGetLastError();
 }
 

@@ -439,7 +439,11 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         TR_PROF(5, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, s); })));
       }
       {
-        WgradArgs a;   // d W1 = d pre x [x taps | spect]^T, d b1
+        // d W1 = d pre x [x taps | spect]^T, d b1;
+        // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
+        // job with the d out plane appended to the d x planes (the last layer has no d x: d out alone).
+        // Both jobs in ONE launch: the short workgroups of the second fill the idle slots of the first one's last round.
+        WgradArgs a, a2;
         memset(&a, 0, sizeof a);
         a.G = GPi;
         a.m_chunks = 2 * cc;
@@ -454,26 +458,20 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.out = w.slab;
         a.out_scale = 1.0f;
         a.bias_out = w.part;
-        TR_PROF(6, TR_TRY(launch_wgrad(a, s)));
-      }
-      {
-        // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
-        // launch with the d out plane appended to the d x planes (the last layer has no d x: d out alone)
-        WgradArgs a;
-        memset(&a, 0, sizeof a);
+        memset(&a2, 0, sizeof a2);
         const int gc = gx ? cc : 0;                 // chunks of d x
-        a.G = gx ? gx : w.GO;
-        a.G_last = gx ? w.GO : nullptr;
-        a.m_chunks = gc + 1;
-        a.n_runs = 1;
-        a.run[0] = run_of(Ai, cc, 0);
-        a.k_chunks = cc;
-        a.g = g;
-        a.row_split = small_split;
-        a.out = w.slab2;
-        a.out_scale = 1.0f;
-        a.bias_out = w.part2;
-        TR_PROF(6, TR_TRY(launch_wgrad(a, s)));
+        a2.G = gx ? gx : w.GO;
+        a2.G_last = gx ? w.GO : nullptr;
+        a2.m_chunks = gc + 1;
+        a2.n_runs = 1;
+        a2.run[0] = run_of(Ai, cc, 0);
+        a2.k_chunks = cc;
+        a2.g = g;
+        a2.row_split = small_split;
+        a2.out = w.slab2;
+        a2.out_scale = 1.0f;
+        a2.bias_out = w.part2;
+        TR_PROF(6, TR_TRY(launch_wgrad(a, &a2, s)));
         // ONE reduction launch for everything the layer's two weight-gradient launches left in their slabs
         const int ns = kPhases * small_split;
         const size_t n1 = (size_t)2 * C * K1, slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
@@ -571,7 +569,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.out = gr->dwup;
     a.out_scale = inv;
     a.bias_out = w.part;
-    TR_TRY(launch_wgrad(a, s));
+    TR_TRY(launch_wgrad(a, nullptr, s));
     TR_TRY(launch_slab_reduce(w.part, kPhases, M8, M8, inv, gr->dbup, s));
   }
   return WG_OK;

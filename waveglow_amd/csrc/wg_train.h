@@ -107,7 +107,8 @@ struct StartWgradArgs {
 
 hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s);
 void set_plane_gemm_stamps(unsigned long long* device_buffer);   // diagnostics: [workgroups][4] s_memtime of the gate GEMM
-hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+// one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle
+hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
 hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
                               hipStream_t s);
