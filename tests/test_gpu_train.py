@@ -135,6 +135,20 @@ def test_train_step_both_layer_tile_widths(force_bn, monkeypatch):
     _check(grads, g_ref, f"bn{force_bn}/c{hp.n_channels}")
 
 
+@pytest.mark.parametrize("slabs", ["1,4", "2,2", "4,1", "2,4"])
+def test_train_step_every_slab_shape(slabs, monkeypatch):
+  """The weight-gradient kernel writes one fp32 slab per workgroup row range: a phase, 1/2 or 1/4 of a phase, or 2 / 4
+  consecutive phases (large shapes pick fewer slabs, which small test shapes would never see).  Every combination for
+  the two jobs of a layer, against the oracle."""
+  from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_TRAIN_SLABS", slabs)
+  hp, sd, mel, wav = _setup(dict(n_layers=3, n_flows=2, n_early_every=1, n_early_size=2), 3, 11, 8, crop=56)
+  loss, y, grads = _gpu_step(hp, sd, mel, wav)
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check(grads, g_ref, f"slabs {slabs}")
+
+
 @pytest.mark.parametrize("ct", ["2", "3", "4", "6"])
 def test_train_step_every_tile_width(ct, monkeypatch):
   """Rp = 384 rows per phase divides by 64, 96, 128 and 192: every tile width of the plane GEMM gives the same

@@ -403,7 +403,7 @@ struct WgradPair {
   unsigned nwg[2];        // workgroups of each job (the second may be 0)
 };
 inline unsigned wgrad_workgroups(const WgradArgs& a) {
-  return (unsigned)((a.m_chunks + 3) / 4) * (unsigned)((a.k_chunks + 1) / 2) * (unsigned)(kPhases * a.row_split);
+  return (unsigned)((a.m_chunks + 3) / 4) * (unsigned)((a.k_chunks + 1) / 2) * (unsigned)(kPhases * a.row_split / a.phases_per_slab);
 }
 }  // namespace
 
@@ -418,7 +418,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   const unsigned wgid = xcd_order(second ? blockIdx.x - pr.nwg[0] : blockIdx.x, second ? pr.nwg[1] : pr.nwg[0]);
   const int bx = (int)(wgid % gx), by = (int)((wgid / gx) % gy);
   const int slab = (int)(wgid / (gx * gy));
-  const int p = slab / a.row_split, rs = slab - p * a.row_split;
+  const int pps = a.phases_per_slab;
+  const int p0 = pps > 1 ? slab * pps : slab / a.row_split, rs = pps > 1 ? 0 : slab - p0 * a.row_split;
   const int rows_per = g.Rp / a.row_split;
   const int mc0 = bx * 4, kc0 = by * 2;
   const size_t R64 = (size_t)g.R * 64;
@@ -429,16 +430,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int gch = (mc0 + e < a.m_chunks) ? mc0 + e : a.m_chunks - 1;
     return (a.G_last && gch == a.m_chunks - 1) ? a.G_last : a.G + (size_t)gch * R64;
   };
-  const size_t grow0 = (size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + 8 * rb;
-  const char* src0 = uniform_ptr(g_chunk_base(w >> 2) + grow0 * 64);
-  const char* src1 = uniform_ptr(g_chunk_base(2 + (w >> 2)) + grow0 * 64);
-  const char* src2;
+  const _Float16* const gb0 = g_chunk_base(w >> 2);
+  const _Float16* const gb1 = g_chunk_base(2 + (w >> 2));
+  const _Float16* xb;
+  int xdt;
   {
     int c = (kc0 + (w >> 2) < a.k_chunks) ? kc0 + (w >> 2) : a.k_chunks - 1;
     int i = 0;
     while (c >= a.run[i].n_chunks) { c -= a.run[i].n_chunks; ++i; }
-    src2 = uniform_ptr(a.run[i].base + (size_t)c * R64 + (shifted_row(g, p, a.run[i].dt) + (size_t)rs * rows_per + 8 * rb) * 64);
+    xb = a.run[i].base + (size_t)c * R64;
+    xdt = a.run[i].dt;
   }
+  const char *src0, *src1, *src2;
+  auto set_phase = [&](int p) {
+    const size_t grow0 = (size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + 8 * rb;
+    src0 = uniform_ptr(gb0 + grow0 * 64);
+    src1 = uniform_ptr(gb1 + grow0 * 64);
+    src2 = uniform_ptr(xb + (shifted_row(g, p, xdt) + (size_t)rs * rows_per + 8 * rb) * 64);
+  };
   // lane -> (row lr of the 8-row block, 16-byte slot): fetches piece slot ^ (key << 1) of its row, key = (row >> 1) & 3
   const int lr = lane >> 3;
   const unsigned voff = (unsigned)(lr * 128 + (((lane & 7) ^ (((lr >> 1) & 3) << 1)) << 4));
@@ -488,6 +497,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   };
 
   const int n_steps = rows_per / WG_STEP;
+  for (int ph = 0; ph < pps; ++ph) {
+  if (ph) __syncthreads();          // the last step's stage has been read by every wave before it is refilled
+  set_phase(p0 + ph);
   issue(0);
   if (n_steps > 1) issue(1);
   for (int st = 0; st < n_steps; ++st) {
@@ -517,6 +529,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
       for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
   }
 
   // D: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -548,6 +561,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 namespace {
 hipError_t check_wgrad(const WgradArgs& a) {
   if (a.n_runs < 1 || a.n_runs > kMaxRuns || a.row_split < 1 || a.g.Rp % (a.row_split * WG_STEP)) return hipErrorInvalidValue;
+  if (a.phases_per_slab < 1 || kPhases % a.phases_per_slab || (a.phases_per_slab > 1 && a.row_split != 1)) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks;
   if (k != a.k_chunks || a.m_chunks < 1) return hipErrorInvalidValue;

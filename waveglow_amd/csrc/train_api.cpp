@@ -347,8 +347,6 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   const int C = x.C, nl = x.nl, M8 = x.M8, K1 = x.K1, FL = x.FL;
   const int cc = C / 64, mc = M8 / 64;
   const float inv = 1.0f / scale;
-  // the C x C and 64 x C weight gradients have few output tiles: cut every phase's rows into parts (more slabs)
-  const int small_split = 4;                           // Rp is a multiple of 128 = 4 parts of whole 32-row steps
   const _Float16* wat = (const _Float16*)wt->wat;
   const _Float16* wbt = (const _Float16*)wt->wbt;
   // fragment tensors of the two dgrad GEMMs (include/waveglow_amd.h: wat, wbt): elements per 64-deep K-step and per layer
@@ -360,6 +358,18 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
       n_cu = v;
+  }
+  // Slabs of the weight-gradient jobs (Rp is a multiple of 128 = up to 4 parts of whole 32-row steps).  Every slab is
+  // written once and read once by the reduction, so as few as still fill the chip: the small job (4 tiles at 256
+  // channels) cuts a phase in 2 (256 workgroups) rather than 4.  The big job (22 tiles) keeps one slab per phase:
+  // two phases per workgroup (16 slabs, 352 workgroups of 144 steps) halved its slab bytes but measured 0.8 ms per
+  // step slower in the kernel than it saved in the reduction (config 4, MI355X).
+  const int small_tiles = ((cc + 1 + 3) / 4) * ((cc + 1) / 2);
+  int big_pps = 1;
+  int small_split = (small_tiles * kPhases * 2 >= n_cu) ? 2 : 4;
+  if (const char* e = getenv("WG_TRAIN_SLABS")) {      // tests: "<phases per slab of d W1>,<row split of d W2>"
+    int a_ = 0, b_ = 0;
+    if (sscanf(e, "%d,%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2 || a_ == 4) && (b_ == 1 || b_ == 2 || b_ == 4)) { big_pps = a_; small_split = b_; }
   }
   int BNw = wn_block_n(C);
   if (BNw == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)n_cu) BNw = 64;
@@ -455,6 +465,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.k_chunks = 3 * cc + mc;
         a.g = g;
         a.row_split = 1;
+        a.phases_per_slab = big_pps;
         a.out = w.slab;
         a.out_scale = 1.0f;
         a.bias_out = w.part;
@@ -468,6 +479,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a2.k_chunks = cc;
         a2.g = g;
         a2.row_split = small_split;
+        a2.phases_per_slab = 1;
         a2.out = w.slab2;
         a2.out_scale = 1.0f;
         a2.bias_out = w.part2;
@@ -482,8 +494,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
           seg[nseg].n_slabs = n_slabs; seg[nseg].scale = inv;
           ++nseg;
         };
-        add(w.slab, kPhases, n1, n1, gr->dw1 + gofs(fl, n1));
-        add(w.part, kPhases, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C));
+        add(w.slab, kPhases / big_pps, n1, n1, gr->dw1 + gofs(fl, n1));
+        add(w.part, kPhases / big_pps, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C));
         if (gx) {
           add(w.slab2, ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C));
           add(w.part2, ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C));
@@ -566,6 +578,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.k_chunks = 8;
     a.g = g;
     a.row_split = 1;
+    a.phases_per_slab = 1;
     a.out = gr->dwup;
     a.out_scale = inv;
     a.bias_out = w.part;

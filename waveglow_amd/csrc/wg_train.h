@@ -53,7 +53,8 @@ struct PGemmArgs {
 };
 
 // dW[m][k'] = sum over the rows of one slab of G[row][m] * X[row(+shift)][k']  -> out[slab][m][k'] * out_scale
-// slab = phase * row_split + part: a phase's Rp rows are cut into row_split parts (small GEMMs: more workgroups)
+// slab = phase * row_split + part: a phase's Rp rows are cut into row_split parts (small GEMMs: more workgroups);
+// or slab = phase / phases_per_slab (large GEMMs: fewer, longer workgroups -- half the slab bytes to write and reduce)
 struct WgradArgs {
   const _Float16* G;        // planes [m_chunks][R][64]  (the last chunk comes from G_last when that is set)
   const _Float16* G_last;   // optional: one more 64-channel plane appended to G (e.g. the d out plane behind d x)
@@ -63,7 +64,8 @@ struct WgradArgs {
   int k_chunks;             // sum n_chunks
   RowGeom g;
   int row_split;            // 1, 2 or 4
-  float* out;               // [32*row_split slabs][m_chunks*64][k_chunks*64] fp32
+  int phases_per_slab;      // 1, or (row_split == 1 only) 2 / 4: one workgroup runs that many consecutive phases into one slab
+  float* out;               // [32*row_split/phases_per_slab slabs][m_chunks*64][k_chunks*64] fp32
   float out_scale;
   float* bias_out;          // optional [slabs][m_chunks*64]: sum over the slab's rows of G (bias gradients), unscaled
 };
