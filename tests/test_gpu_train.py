@@ -135,6 +135,32 @@ def test_train_step_both_layer_tile_widths(force_bn, monkeypatch):
     _check(grads, g_ref, f"bn{force_bn}/c{hp.n_channels}")
 
 
+@pytest.mark.parametrize("over,B", [(dict(n_layers=3, n_flows=3, n_early_every=1, n_early_size=2), 2),
+                                    (dict(n_channels=64, n_layers=8, n_flows=4, n_early_every=2), 4)])
+def test_train_step_half_batch_chains(over, B, monkeypatch):
+  """Large batches run as two half-batch chains on two streams, with the weight-gradient launches on a third (train_api.cpp:
+  setup, wg_train_backward_flows); small test shapes would never choose that, so it is forced here.  The same step with
+  everything serialised on one stream must give bit-identical outputs and gradients (the streams only reorder launches
+  that do not depend on each other -- any difference is a missing dependency), and both match the oracle."""
+  from oracle import torch_oracle as O
+  hp, sd, mel, wav = _setup(over, B, 11, 9, crop=56)
+  monkeypatch.setenv("WG_TRAIN_HALVES", "2")
+  monkeypatch.setenv("WG_TRAIN_BWD_HALVES", "2")
+  monkeypatch.setenv("WG_TRAIN_SERIAL", "1")
+  loss_s, y_s, g_s = _gpu_step(hp, sd, mel, wav)
+  monkeypatch.setenv("WG_TRAIN_SERIAL", "0")
+  for rep in range(3):
+    monkeypatch.setenv("WG_TRAIN_BWD_HALVES", "2" if rep < 2 else "1")       # the default: one chain + the weight-gradient stream
+    loss_c, y_c, g_c = _gpu_step(hp, sd, mel, wav)
+    assert loss_c == loss_s
+    assert torch.equal(y_c[0].detach().cpu(), y_s[0].detach().cpu())
+    for name in g_s:
+      assert torch.equal(g_c[name], g_s[name]), f"{name}: chains differ from the serial run (rep {rep})"
+  loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(loss_c - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check(g_c, g_ref, f"chains c{hp.n_channels}")
+
+
 @pytest.mark.parametrize("slabs", ["1,4", "2,2", "4,1", "2,4"])
 def test_train_step_every_slab_shape(slabs, monkeypatch):
   """The weight-gradient kernel writes one fp32 slab per workgroup row range: a phase, 1/2 or 1/4 of a phase, or 2 / 4

@@ -123,6 +123,11 @@ struct wg_handle {
   size_t ev_used = 0;
   double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // library-owned streams of the training direction (independent chains of one call run side by side, joined back into
+  // the caller's stream before the call returns) and a ring of ordering events for them
+  hipStream_t aux[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> sync_ev;
+  size_t sync_next = 0;
 };
 
 namespace {
@@ -229,6 +234,39 @@ void wg_internal_prof_event(wg_handle* h, void* s, int cls) {
   hipEventRecord(h->ev[h->ev_used++], (hipStream_t)s);
 }
 
+// Library-owned stream i (0: second chain, normal priority; 1: work with slack, lowest priority) of the handle's device.
+hipStream_t wg_internal_aux_stream(wg_handle* h, int i) {
+  if (!h || i < 0 || i > 1) return nullptr;
+  if (!h->aux[i]) {
+    int lo = 0, hi = 0, prev = -1;
+    hipStream_t st = nullptr;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != h->device) (void)hipSetDevice(h->device);
+    if (i == 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+      if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
+    }
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
+    h->aux[i] = st;
+  }
+  return h->aux[i];
+}
+// Next event of the ordering ring (no timing).  A wait captures the record that precedes it in host order, so an event
+// may be recorded again while earlier waits on it are still pending on the device.
+hipEvent_t wg_internal_sync_event(wg_handle* h) {
+  constexpr size_t kRing = 1024;
+  if (!h) return nullptr;
+  if (h->sync_ev.size() < kRing) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    h->sync_ev.push_back(e);
+    return e;
+  }
+  hipEvent_t e = h->sync_ev[h->sync_next];
+  h->sync_next = (h->sync_next + 1) % kRing;
+  return e;
+}
+
 extern "C" {
 
 const char* wg_version(void) { return "waveglow_amd 0.1 (gfx950)"; }
@@ -284,6 +322,9 @@ int wg_destroy(wg_handle* h) {
   if (h->d_blob) hipFree(h->d_blob);
   if (h->d_cond) hipFree(h->d_cond);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
+  for (hipStream_t st : h->aux)
+    if (st) hipStreamDestroy(st);
   delete h;
   return WG_OK;
 }

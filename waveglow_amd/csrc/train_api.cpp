@@ -17,6 +17,8 @@ const wg_config* wg_internal_config(const wg_handle* h);                  // api
 const int* wg_internal_flow_channels(const wg_handle* h);                 // api.cpp
 wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T);    // api.cpp
 void wg_internal_prof_event(wg_handle* h, void* stream, int cls);         // api.cpp
+hipStream_t wg_internal_aux_stream(wg_handle* h, int i);                  // api.cpp
+hipEvent_t wg_internal_sync_event(wg_handle* h);                          // api.cpp
 
 namespace {
 
@@ -28,7 +30,7 @@ namespace {
       return wg_set_error(WG_ERR_HIP, m.c_str());                                            \
     }                                                                                        \
     if (dbg_sync()) {                                                                        \
-      hipError_t _s = hipStreamSynchronize(s);                                               \
+      hipError_t _s = hipDeviceSynchronize();                                                \
       fprintf(stderr, "[wg-train] %s -> %s\n", #expr, hipGetErrorString(_s));                \
       fflush(stderr);                                                                        \
       if (_s != hipSuccess) return wg_set_error(WG_ERR_HIP, hipGetErrorString(_s));          \
@@ -36,11 +38,11 @@ namespace {
   } while (0)
 
 // per-class device timing of the training launches (wg_profile_enable / wg_profile_read, classes 4..7)
-#define TR_PROF(cls, stmt)                         \
+#define TR_PROF(st, cls, stmt)                      \
   do {                                             \
-    wg_internal_prof_event(h, (void*)s, cls);      \
+    wg_internal_prof_event(h, (void*)(st), cls);   \
     stmt;                                          \
-    wg_internal_prof_event(h, (void*)s, cls);      \
+    wg_internal_prof_event(h, (void*)(st), cls);   \
   } while (0)
 
 bool dbg_sync() {
@@ -58,11 +60,12 @@ struct TrainWs {
   // fp16 planes (elements)
   _Float16 *X, *T, *S, *A;      // [FL] x C/64 chunks each (plane_c elements per fl)
   _Float16 *GP;                 // [FL] x 2C/64 chunks, contiguous: the K operand of the cond_layer dgrad
-  _Float16 *GX0, *GX1, *GO, *SP, *MELP, *GSP;
+  _Float16 *GXL;                // [n_layers] x C/64 chunks: d x_i of the flow in flight (one buffer per layer: see chains)
+  _Float16 *GO[2], *SP, *MELP, *GSP;   // d out plane (per flow parity), spectrogram planes, mel planes, d spect planes
   float *Zpost, *OUT;           // [n_flows][B*L*8]
   float *GZ;                    // [B*L*8]
   float *slab, *slab2;          // wgrad phase slabs (dW1 | dW2 + end x skip: both alive until the layer's one reduction launch)
-  float *part, *part2;          // column-sum / row-kernel partials
+  float *part, *part2, *part3;  // column-sum partials of the two weight-gradient jobs / of the row kernels of a flow
   size_t plane_c;               // elements of one C-channel plane set
   size_t rows8;                 // B*L*8
   size_t zero_bytes;            // prefix that `fresh` clears (all planes)
@@ -81,9 +84,9 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.S = (_Float16*)take((size_t)FL * w.plane_c * 2);
   w.A = (_Float16*)take((size_t)FL * w.plane_c * 2);
   w.GP = (_Float16*)take((size_t)FL * 2 * w.plane_c * 2);
-  w.GX0 = (_Float16*)take(w.plane_c * 2);
-  w.GX1 = (_Float16*)take(w.plane_c * 2);
-  w.GO = (_Float16*)take(chunk * 2);
+  w.GXL = (_Float16*)take((size_t)c.n_layers * w.plane_c * 2);
+  w.GO[0] = (_Float16*)take(chunk * 2);
+  w.GO[1] = (_Float16*)take(chunk * 2);
   w.SP = (_Float16*)take((size_t)(M8 / 64) * chunk * 2);
   w.MELP = (_Float16*)take(2 * chunk * 2);
   w.GSP = (_Float16*)take((size_t)(M8 / 64) * chunk * 2);
@@ -95,11 +98,9 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   const size_t K1 = 3 * (size_t)C + M8;
   w.slab = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
   w.slab2 = (float*)take((size_t)kPhases * 4 * (C + 64) * C * 4);          // row_split 4: [128 slabs][(C/64 + 1) * 64][C]
-  size_t part = (size_t)kPhases * 4 * max_sz(2 * (size_t)C, (size_t)M8);     // bias partials: [slabs][rows]
-  part = max_sz(part, (size_t)flow_bwd_workgroups(g) * 64);
-  part = max_sz(part, (size_t)start_wgrad_workgroups(g) * 5 * C);
-  w.part = (float*)take(part * 4);
+  w.part = (float*)take((size_t)kPhases * 4 * max_sz(2 * (size_t)C, (size_t)M8) * 4);     // bias partials: [slabs][rows]
   w.part2 = (float*)take((size_t)kPhases * 4 * (C + 64) * 4);
+  w.part3 = (float*)take(max_sz((size_t)flow_bwd_workgroups(g) * 64, (size_t)start_wgrad_workgroups(g) * 5 * C) * 4);
   w.bytes = off;
   return w;
 }
@@ -110,7 +111,26 @@ struct Ctx {
   RowGeom g;
   TrainWs w;
   int C, FL, M8, K1, nl;
+  int n_cu;
+  int halves;      // 2: the batch runs as two independent half-batch chains (see setup)
+  bool serial;     // WG_TRAIN_SERIAL=1: everything on the caller's stream (profiling of single kernels, A/B runs)
 };
+
+// sets rc_ and returns from the enclosing function on a HIP error of an ordering call
+#define TR_ORDER(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return wg_set_error(WG_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+  } while (0)
+
+// `to` continues after everything enqueued on `from` so far
+hipError_t order_after(wg_handle* h, hipStream_t from, hipStream_t to) {
+  if (from == to) return hipSuccess;
+  hipEvent_t e = wg_internal_sync_event(h);
+  if (!e) return hipErrorOutOfMemory;
+  hipError_t r = hipEventRecord(e, from);
+  return r != hipSuccess ? r : hipStreamWaitEvent(to, e, 0);
+}
 
 int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* workspace, size_t workspace_bytes, Ctx& x) {
   if (!h) return wg_set_error(WG_ERR_INVALID, "null handle");
@@ -123,6 +143,40 @@ int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* wo
     return wg_set_error(WG_ERR_INVALID, "upsampled mel shorter than audio");
   const int L = audio_len / c.n_group;
   x.g = wg_internal_geom(h, B, L, n_frames);
+  x.n_cu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      x.n_cu = v;
+  }
+  // Chains.  A WN-layer launch runs ceil(tiles / CUs) rounds and the next layer waits for its last, partly filled
+  // round (config 4: 576 tiles of 128 columns on 256 CUs = 2.25 rounds, a quarter of the chip-time idle).  The two
+  // halves of the batch never exchange data inside a WN, so they run as two chains of half-size launches on two
+  // streams and fill each other's idle CUs.  That needs the first B/2 utterances to end on a tile boundary: the rows
+  // per utterance Fp are padded up (71 -> 72 at config 4: 16 x 72 = 9 tiles, the same 2304 rows per phase as before).
+  // Rows past an utterance's last frame are guard rows like the others: never valid, always written as zeros -- the
+  // only rows of the other half a chain's dilated taps can reach.
+  x.halves = 1;
+  {
+    const char* e = getenv("WG_TRAIN_HALVES");
+    const int want = e ? atoi(e) : 0;               // 1: never, 2: always (tests), otherwise by shape
+    if (B % 2 == 0 && want != 1) {
+      int fp = x.g.Fp;
+      while ((B / 2 * fp) % 128) ++fp;
+      const int rp = B * fp;
+      const long long tiles = (long long)kPhases * (x.g.Rp / 128);
+      const long long idle = (tiles + x.n_cu - 1) / x.n_cu * x.n_cu - tiles;
+      const bool helps = tiles > x.n_cu && idle * 10 >= tiles && rp <= x.g.Rp + x.g.Rp / 32;
+      if (want == 2 || helps) {
+        x.g.Fp = fp;
+        x.g.Rp = rp;
+        x.g.R = kPhases * rp + 2 * kRowPad;
+        x.halves = 2;
+      }
+    }
+    const char* se = getenv("WG_TRAIN_SERIAL");
+    x.serial = se && *se == '1';
+  }
   x.w = carve(c, x.g, (char*)workspace);
   if (workspace && x.w.bytes > workspace_bytes) return wg_set_error(WG_ERR_WORKSPACE, "training workspace too small");
   if ((size_t)x.g.R * 128 >= (1ull << 32)) return wg_set_error(WG_ERR_INVALID, "plane too large for 32-bit offsets");
@@ -154,15 +208,15 @@ int check_grads(const wg_train_grads* g, int n_flows) {
   return WG_OK;
 }
 
-// One WN-layer-kernel GEMM over every column of the planes.  (Measured and dropped: splitting a layer whose tile count
-// is not a multiple of the CU count -- config 4: 576 tiles of 128 columns = 2.25 rounds -- into a whole-rounds launch of
-// 128-column tiles and a tail launch of 64-column tiles.  A 64-column tile streams the same A fragments and takes ~80 % of
-// a 128-column tile's time (the K loop is VMEM-issue bound), so 2 + 0.8 rounds plus a second launch is no faster than 3.)
+// One WN-layer-kernel GEMM over part `part` of `parts` equal row ranges of every phase (parts = 1: every column).
+// (Measured and dropped: splitting a layer whose tile count is not a multiple of the CU count into a whole-rounds
+// launch of 128-column tiles and a tail launch of 64-column tiles on the same stream.  A 64-column tile streams the same
+// A fragments and takes ~80 % of a 128-column tile's time, so 2 + 0.8 rounds plus a second launch is no faster than 3.)
 template <class Launch>
-hipError_t launch_rounds(WnLayerArgs a, const RowGeom& g, int bn, int n_cu, Launch launch) {
-  (void)n_cu;
-  a.row0 = 0;
-  a.tiles_per_phase = g.Rp / bn;
+hipError_t launch_part(WnLayerArgs a, const RowGeom& g, int bn, int part, int parts, Launch launch) {
+  const int rows = g.Rp / parts;
+  a.row0 = part * rows;
+  a.tiles_per_phase = rows / bn;
   a.n_tiles = kPhases * a.tiles_per_phase;
   return launch(a, bn);
 }
@@ -211,11 +265,12 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
   const int NW = wn_waves(C), MBw = C / (32 * NW), MTw = 2 * MBw;
   const size_t a1_n = (size_t)2 * (3 * cc) * NW * MTw * 2 * 64 * 8, a1c_n = (size_t)2 * mc * NW * MTw * 2 * 64 * 8;
   const size_t a2_n = (size_t)NW * MBw * (C / 16) * 64 * 8, es_n = (size_t)(C / 32) * 64 * 8;
-  int n_cu = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n_cu = v;
+  const int n_cu = x.n_cu;
+  // second chain (the caller's stream is the first): see setup
+  hipStream_t sB = s;
+  if (x.halves == 2 && !x.serial) {
+    sB = wg_internal_aux_stream(h, 0);
+    if (!sB) return wg_set_error(WG_ERR_HIP, "cannot create the second chain's stream");
   }
   // tile width of the fused layer kernel: as the inference path chooses it (api.cpp: run_wn)
   int BNw = wn_block_n(C);
@@ -283,6 +338,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
     }
     TR_TRY(launch_flow(f, s));
     if (f.last) break;
+    TR_ORDER(order_after(h, s, sB));
     for (int i = 0; i < nl; ++i) {
       const int fl = k * nl + i, d = 1 << i;
       const _Float16* Xi = w.X + (size_t)fl * w.plane_c;
@@ -314,9 +370,13 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
         a.save_t = w.T + (size_t)fl * w.plane_c;
         a.save_s = w.S + (size_t)fl * w.plane_c;
         a.save_a = Ai;
-        TR_PROF(4, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_layer_train(q, C, bn, s); })));
+        for (int half = 0; half < x.halves; ++half) {
+          hipStream_t sh = half ? sB : s;
+          TR_PROF(sh, 4, TR_TRY(launch_part(a, g, BNw, half, x.halves, [&](const WnLayerArgs& q, int bn) { return launch_wn_layer_train(q, C, bn, sh); })));
+        }
       }
     }
+    TR_ORDER(order_after(h, sB, s));
   }
   return WG_OK;
 }
@@ -353,11 +413,20 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   const int NW = wn_waves(C), MBw = C / (32 * NW);
   const size_t kstep_n = (size_t)2 * NW * MBw * 2 * 64 * 8;
   const size_t wat_n = (size_t)(cc + 1) * kstep_n, wbt_n = (size_t)(6 * cc) * kstep_n;
-  int n_cu = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n_cu = v;
+  const int n_cu = x.n_cu;
+  // Streams of one backward call.  The caller's stream `s` carries chain 0 (d acts / gate derivative and d x of the
+  // first half of the batch) and the row kernels of every flow; sB carries chain 1 (the second half, see setup); sW
+  // (lowest priority) carries the weight-gradient launches and their slab reductions, which nothing downstream in
+  // the same call waits for: they fill the CUs the chains leave idle.  Everything is joined back into `s` before the
+  // call returns, so the caller sees the usual stream semantics.  WG_TRAIN_SERIAL=1: all three are `s`.
+  // (Two chains pay in the forward pass, -23 % per layer at config 4; in the backward pass the weight-gradient stream
+  //  already fills the idle CUs and a second chain measured +0.7 ms per step: off unless WG_TRAIN_BWD_HALVES=2, tests.)
+  int bh = 1;
+  if (const char* e = getenv("WG_TRAIN_BWD_HALVES")) bh = (atoi(e) == 2) ? x.halves : 1;
+  hipStream_t sB = s, sW = s;
+  if (!x.serial) {
+    if (bh == 2 && !(sB = wg_internal_aux_stream(h, 0))) return wg_set_error(WG_ERR_HIP, "cannot create the second chain's stream");
+    if (!(sW = wg_internal_aux_stream(h, 1))) return wg_set_error(WG_ERR_HIP, "cannot create the weight-gradient stream");
   }
   // Slabs of the weight-gradient jobs (Rp is a multiple of 128 = up to 4 parts of whole 32-row steps).  Every slab is
   // written once and read once by the reduction, so as few as still fill the chip: the small job (4 tiles at 256
@@ -395,6 +464,22 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   };
   int z_final_ch0 = early_channels_upto(flow_hi);
 
+  // Buffers the streams share and what orders their reuse:
+  //   GXL[i] (d x_i)   written by the chains' d x launch of layer i, read by their layer i-1 launches (same stream) and by
+  //                    sW's second job of layer i-1: the next flow's layer-i launch waits for that job (w_done[i-1]);
+  //   GO[k & 1]        written by flow k's pre kernel on s, read by the chains and by all of flow k's jobs on sW: the pre
+  //                    kernel of flow k-2 waits for the last of them (w_flow[k & 1]);
+  //   GP, X, T, S, A   one set per layer of the whole model: no reuse inside a call.
+  TR_ORDER(order_after(h, s, sW));
+  hipEvent_t w_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, w_flow[2] = {nullptr, nullptr};
+  auto mark = [&](hipStream_t st, hipEvent_t& e) -> hipError_t {
+    e = nullptr;
+    if (x.serial) return hipSuccess;
+    e = wg_internal_sync_event(h);
+    return e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
+  };
+  auto wait_for = [&](hipStream_t st, hipEvent_t e) -> hipError_t { return e ? hipStreamWaitEvent(st, e, 0) : hipSuccess; };
+
   for (int k = flow_hi; k >= flow_lo; --k) {
     const int ck = x.ck[k], hk = ck / 2;
     FlowBwdArgs fb;
@@ -411,10 +496,13 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     fb.from_z = (k == c.n_flows - 1);
     fb.z_ch0 = early_channels_upto(c.n_flows - 1);
     fb.GZ = w.GZ;
-    fb.GO = w.GO;
+    _Float16* const GOk = w.GO[k & 1];
+    fb.GO = GOk;
+    TR_ORDER(wait_for(s, w_flow[k & 1]));
     TR_TRY(launch_flow_bwd_pre(fb, s));
+    TR_ORDER(order_after(h, s, sB));
 
-    _Float16 *gx = nullptr, *gx_next = w.GX0;   // gx = d x_{i+1} (null: zero, the last layer has no res output)
+    _Float16* gx = nullptr;                     // gx = d x_{i+1} (null: zero, the last layer has no res output)
     for (int i = nl - 1; i >= 0; --i) {
       const int fl = k * nl + i, d = 1 << i;
       const _Float16* Xi = w.X + (size_t)fl * w.plane_c;
@@ -428,12 +516,12 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         if (gx) {
           a.x_tap = gx;
           a.x_chunks_per_tap = cc;
-          a.sp = w.GO;
+          a.sp = GOk;
           a.n_cond_steps = 1;
           a.wA1 = Am;
           a.wA1c = Am + (size_t)cc * kstep_n;
         } else {
-          a.x_tap = w.GO;                    // last layer of a flow: no d x_{i+1}, the d out plane alone
+          a.x_tap = GOk;                     // last layer of a flow: no d x_{i+1}, the d out plane alone
           a.x_chunks_per_tap = 1;
           a.n_cond_steps = 0;
           a.wA1 = Am + (size_t)cc * kstep_n;
@@ -446,7 +534,13 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.in0 = w.T + (size_t)fl * w.plane_c;
         a.in1 = w.S + (size_t)fl * w.plane_c;
         a.out0 = GPi;
-        TR_PROF(5, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, s); })));
+        for (int half = 0; half < bh; ++half) {
+          hipStream_t sh = half ? sB : s;
+          TR_PROF(sh, 5, TR_TRY(launch_part(a, g, BNw, half, bh, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, sh); })));
+        }
+        // the weight-gradient stream continues once both chains have written their half of d pre (and of d x_{i+1} before it)
+        TR_ORDER(order_after(h, s, sW));
+        TR_ORDER(order_after(h, sB, sW));
       }
       {
         // d W1 = d pre x [x taps | spect]^T, d b1;
@@ -471,8 +565,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.bias_out = w.part;
         memset(&a2, 0, sizeof a2);
         const int gc = gx ? cc : 0;                 // chunks of d x
-        a2.G = gx ? gx : w.GO;
-        a2.G_last = gx ? w.GO : nullptr;
+        a2.G = gx ? gx : GOk;
+        a2.G_last = gx ? GOk : nullptr;
         a2.m_chunks = gc + 1;
         a2.n_runs = 1;
         a2.run[0] = run_of(Ai, cc, 0);
@@ -483,7 +577,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a2.out = w.slab2;
         a2.out_scale = 1.0f;
         a2.bias_out = w.part2;
-        TR_PROF(6, TR_TRY(launch_wgrad(a, &a2, s)));
+        TR_PROF(sW, 6, TR_TRY(launch_wgrad(a, &a2, sW)));
         // ONE reduction launch for everything the layer's two weight-gradient launches left in their slabs
         const int ns = kPhases * small_split;
         const size_t n1 = (size_t)2 * C * K1, slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
@@ -503,7 +597,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         add(w.slab2 + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C));
         // d out_init = sum over columns of (d b | d log_s), once per flow
         if (i == 0) add(w.part2 + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k]);
-        TR_TRY(launch_slab_reduce_multi(seg, nseg, s));
+        TR_TRY(launch_slab_reduce_multi(seg, nseg, sW));
+        TR_ORDER(mark(sW, w_done[i]));
       }
       {
         // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)   (wn_layer_kernel MODE 2: taps at +d, 0, -d)
@@ -519,12 +614,18 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.M = c.n_mel_channels;
         a.n_cu = n_cu;
         a.in0 = gx;
-        a.out0 = gx_next;
-        TR_PROF(5, TR_TRY(launch_rounds(a, g, BNw, n_cu, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 2, bn, s); })));
-        gx = gx_next;
-        gx_next = (gx == w.GX0) ? w.GX1 : w.GX0;
+        _Float16* const gxi = w.GXL + (size_t)i * w.plane_c;
+        a.out0 = gxi;
+        for (int half = 0; half < bh; ++half) {
+          hipStream_t sh = half ? sB : s;
+          if (i > 0) TR_ORDER(wait_for(sh, w_done[i - 1]));     // the previous flow's reader of GXL[i] (not yet re-marked: layer i-1 of this flow comes later)
+          TR_PROF(sh, 5, TR_TRY(launch_part(a, g, BNw, half, bh, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 2, bn, sh); })));
+        }
+        gx = gxi;
       }
     }
+    TR_ORDER(mark(sW, w_flow[k & 1]));
+    TR_ORDER(order_after(h, sB, s));
     {
       StartWgradArgs a;
       a.g = g;
@@ -532,9 +633,9 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
       a.h = hk;
       a.GX = gx;
       a.Zpost = fb.Zpost;
-      a.partial = w.part;
+      a.partial = w.part3;
       TR_TRY(launch_start_wgrad(a, s));
-      TR_TRY(launch_slab_reduce(w.part, start_wgrad_workgroups(g), (size_t)5 * C, (size_t)5 * C, inv, gr->dstart[k], s));
+      TR_TRY(launch_slab_reduce(w.part3, start_wgrad_workgroups(g), (size_t)5 * C, (size_t)5 * C, inv, gr->dstart[k], s));
     }
     fb.GX = gx;
     fb.wstart = wt->wstart[k];
@@ -549,10 +650,11 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     } else {
       fb.audio = (const float*)audio;
     }
-    fb.dw_partial = w.part;
+    fb.dw_partial = w.part3;
     TR_TRY(launch_flow_bwd_post(fb, s));
-    TR_TRY(launch_slab_reduce(w.part, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], s));
+    TR_TRY(launch_slab_reduce(w.part3, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], s));
   }
+  TR_ORDER(order_after(h, sW, s));        // every gradient of the call is final on the caller's stream
   if (flow_lo > 0) return WG_OK;          // the upsample gradient needs the d pre planes of every flow
   {
     // d spect = sum over every layer of cond_layer^T d pre: ONE GEMM with K = FL*2C over the kept d pre planes

@@ -114,7 +114,7 @@ class _Engine:
     return ws
 
 
-  def train_workspace(self, nbytes: int, key: Tuple[int, int, int]) -> Tuple[dict, bool]:
+  def train_workspace(self, nbytes: int, key: Tuple[int, ...]) -> Tuple[dict, bool]:
     """A workspace of the training direction (saved activations) that no pending backward still needs.
     ``fresh`` tells the library to clear it (guard rows must read as zero; they stay zero as long as the geometry
     ``key`` does not change).  Normally there is exactly one; a second forward() before the first backward()

@@ -406,7 +406,7 @@ class _TrainFn(torch.autograd.Function):
     nbytes = lib.wg_train_workspace_bytes(eng.handle, B, F_, S)
     if nbytes == 0:
       raise _lib.WgError(lib.wg_last_error().decode())
-    slot, fresh = eng.train_workspace(nbytes, (B, F_, S))             # held until this graph's backward has run
+    slot, fresh = eng.train_workspace(nbytes, (B, F_, S, nbytes))             # held until this graph's backward has run
     ws = slot["ws"]
     ls = (C.c_void_p * len(log_s))(*[t.data_ptr() for t in log_s])
     stream = torch.cuda.current_stream(mel.device).cuda_stream
