@@ -336,6 +336,8 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
       f.x = w.X + (size_t)(k * nl) * w.plane_c;
       z_ch += f.n_peel;
     }
+    // (measured and dropped: each chain running its own half of the flow step, so that the chains never meet -- they
+    //  drift apart and the forward pass took 0.2-1.0 ms longer than with this join per flow)
     TR_TRY(launch_flow(f, s));
     if (f.last) break;
     TR_ORDER(order_after(h, s, sB));
