@@ -233,7 +233,10 @@ int32_t wg_wn_waves(int32_t n_channels);
 /* Forward with saved activations.  mel [B][n_mel][n_frames] fp32, audio [B][audio_len] fp32 (audio_len % 8 == 0),
  * z [B][8][L] fp32 out, log_s[k] [B][h_k][L] fp32 out.  `fresh` != 0: the workspace has not been used with this
  * geometry before (it is cleared: guard rows must read as zero).  The workspace must stay untouched until
- * wg_train_backward has run.  Enqueue-only. */
+ * wg_train_backward has run.  Enqueue-only.  At large batch the call (and wg_train_backward) also enqueues on two
+ * streams the handle owns: they are forked from `stream` inside the call and joined back into it before it returns,
+ * so the caller sees ordinary stream order.  Environment: WG_TRAIN_SERIAL=1 keeps every launch on `stream`
+ * (timing single kernels); WG_TRAIN_HALVES=1|2 never / always runs the forward as two half-batch chains. */
 int wg_train_forward(wg_handle* h, const wg_train_weights* w, const void* mel, const void* audio, float* z,
                      float* const* log_s, int32_t B, int32_t n_frames, int32_t audio_len, int32_t fresh,
                      void* workspace, size_t workspace_bytes, void* stream);
