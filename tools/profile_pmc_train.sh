@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the training step (tools/bench_train.py), one counter group per run, never combined with tracing.
-# usage: tools/profile_pmc_train.sh <tag>
+# usage: tools/profile_pmc_train.sh <tag>      (export WG_TRAIN_SERIAL=1 first: counters are per kernel, one stream at a time)
 set -u
 TAG=${1:-train}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -17,4 +17,4 @@ run sq3 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES
 run grbm GRBM_GUI_ACTIVE
 run tcc TCC_HIT_sum TCC_MISS_sum
 run fetch FETCH_SIZE
-python3 $ROOT/tools/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1
+python3 $ROOT/tools/summarize_pmc.py $OUT 76 > $OUT/summary.txt 2>&1
