@@ -175,18 +175,20 @@ def test_train_step_every_slab_shape(slabs, monkeypatch):
   _check(grads, g_ref, f"slabs {slabs}")
 
 
-@pytest.mark.parametrize("ct", ["2", "3", "4", "6"])
-def test_train_step_every_tile_width(ct, monkeypatch):
-  """Rp = 384 rows per phase divides by 64, 96, 128 and 192: every tile width of the plane GEMM gives the same
-  gradients (the launcher normally picks the one with the fewest rounds)."""
+@pytest.mark.parametrize("ct,mt", [("2", "5"), ("3", "5"), ("2", "1"), ("3", "1"), ("4", "1"), ("6", "1")])
+def test_train_step_every_tile_width(ct, mt, monkeypatch):
+  """Rp = 384 rows per phase divides by 64, 96, 128 and 192: every tile shape of the plane GEMM (column width x all 640
+  rows in one workgroup or 128-row groups) gives the same gradients (the launcher normally picks the one with the fewest
+  rounds)."""
   from oracle import torch_oracle as O
   monkeypatch.setenv("WG_TRAIN_CT", ct)
+  monkeypatch.setenv("WG_TRAIN_MT", mt)
   over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
   hp, sd, mel, wav = _setup(over, 6, 50, 11, crop=72)
   loss, y, grads = _gpu_step(hp, sd, mel, wav)
   loss_ref, g_ref = O.grads_ref(sd, mel, wav, oracle_cfg_from_hp(hp), 1.0)
   assert abs(loss - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
-  _check(grads, g_ref, "ct" + ct)
+  _check(grads, g_ref, f"ct{ct} mt{mt}")
 
 
 def test_two_forwards_before_backward_and_double_backward():

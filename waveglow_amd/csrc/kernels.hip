@@ -42,7 +42,7 @@ __device__ __forceinline__ float gate_act(float u, float v) {
   return (e1 - 1.0f) * __builtin_amdgcn_rcpf(fmaf(e1, t, t));
 }
 
-// Training forward: the backward pass needs tanh and sigmoid themselves (train.hip: EPI_DGATE), so all three come out of
+// Training forward: the backward pass needs tanh and sigmoid themselves (wn_layer_kernel MODE 3), so all three come out of
 // the same three transcendentals:  r = 1 / ((E1 + 1)(1 + E2)),  acts = (E1 - 1) r,  sigmoid = (E1 + 1) r,
 // tanh = acts (1 + E2).  Both exponents are clamped to +-60 so that every factor stays finite (E2 = inf would make the
 // last product 0 * inf).

@@ -1,10 +1,9 @@
 // gfx950 kernels of the TRAINING direction: WaveGlow.forward with saved activations and its backward pass
 // (reference: src/waveglow/model.py:178-221 under autograd, train.py:190-199 loss.backward()).
 //
-//   plane_gemm_kernel<EPI>  D = A . B over fp16 planes (B = runs of 64-channel planes read at tap offsets), with the
-//                           epilogues of wg_train.h: gate (+ saved tanh / sigmoid), residual add, folded end x skip,
-//                           gate derivative.  Forward GEMM 1 / GEMM 2, both dgrads, the upsample and its dgrad all
-//                           go through it.
+//   plane_gemm_kernel       D = A . B over fp16 planes (B = runs of 64-channel planes read at tap offsets): the upsample
+//                           and the cond_layer dgrad (d spect).  The WN layers themselves run on wn_layer_kernel
+//                           (kernels.hip, MODE 1-3).
 //   wgrad_kernel            dW = G^T-contracted-over-rows X: both operands are [row][channel] planes, so the MFMA
 //                           fragments are fetched with the transposing LDS read ds_read_b64_tr_b16.
 //   row kernels             coupling / 1x1 / start backward, column sums, slab reduction, mel planes.
@@ -49,55 +48,50 @@ __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, in
 }  // namespace
 
 // =============================================================================================
-// plane GEMM.  Workgroup = 4 waves (one per SIMD, up to 512 registers each) = one tile of 32*CT consecutive rows of one
-// phase x 128 matrix rows (x 2 halves for the gate); wave w owns the 32-row block (4*blockIdx.y + w).  The tile is
-// WIDE (CT = 6: 192 columns) because every workgroup streams its rows of A out of L2 once per tile: with 8 waves x
-// 96 columns the gate GEMM was 36 % MFMA-busy and pulled 1.6 GB of weights per launch through L2 (11.7 TB/s); 192
-// columns x half the rows is 4x fewer A bytes per column.  K-step = one 64-channel plane chunk: the B tile
-// (128 rows x 128 B) goes global -> registers -> LDS (XOR-swizzled 16-byte pieces, double buffered, one barrier per
+// plane GEMM  D[M x columns] = A[M x K] . B[K x columns] (+ bias) -> fp16 planes.  Two users per step: the upsample
+// (one [640 x 512] matrix per phase) and d spect = W_cond^T . d pre as ONE GEMM with K = (all layers) x 2C.
+// Workgroup = 4 waves (one per SIMD, up to 512 registers each) = one tile of 32*CT consecutive rows of one phase x
+// 128*MT matrix rows; wave w owns the 32-row blocks w, 4 + w, ... of the group.  MT = 5 covers the 640 spectrogram
+// channels (80 mels x 8) in ONE workgroup: the B tile is staged and read from LDS once, not once per 128-row group
+// (five groups x one ds_read_b128 per MFMA kept the LDS queues full: 47 % MFMA-busy).  K-step = one 64-channel plane
+// chunk: the B tile goes global -> registers -> LDS (XOR-swizzled 16-byte pieces, double buffered, one barrier per
 // step); A comes in MFMA-fragment order [K-step][32-row block][sub-step s][lane][8] (wg_train.h), so a wave's load of
 // one fragment is one contiguous KiB; element j of lane (r, h) in sub-step s is k = 32h + 8s + j of the step, and the
 // B fragment of that sub-step is LDS piece 4h + s of the lane's column -- the K order inside a step is free as long
 // as both operands agree.  (Reading fragments straight from a row-major matrix -- 64 lanes on 64 different cache
 // lines per load -- ran the whole kernel at the L1's line rate: 2.5x slower.)
+// XCD-aware workgroup order: the row groups of one column tile (MT = 1: five of them at M = 640) are consecutive
+// workgroups of one XCD, so the tile's K rows come out of HBM once (6.7 -> 5.5 ms for d spect at config 4).
+// (Round 1 also ran the forward gate / residual / end x skip GEMMs and the gate derivative through this kernel; they
+//  now run on wn_layer_kernel, kernels.hip.)
 // =============================================================================================
-// diagnostics (tools/stamp_train.py): when set, every gate-GEMM workgroup writes s_memtime at 4 phase boundaries
-static unsigned long long* g_pg_stamps = nullptr;
-void set_plane_gemm_stamps(unsigned long long* p) { g_pg_stamps = p; }
-
 constexpr int PG_WAVES = 4;
 constexpr int PG_THREADS = 64 * PG_WAVES;
 
-template <int EPI, int CT>
-__global__ void __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2)))
+template <int CT, int MT>
+__global__ void __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 plane_gemm_kernel(const PGemmArgs a) {
-  constexpr int MT = (EPI == EPI_GATE) ? 2 : 1;
   constexpr int BN = 32 * CT;    // tile width in rows = B-tile rows: CT 16-byte pieces per thread
   __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * 64];
-  unsigned long long tstamp[4];
-  if (EPI == EPI_GATE && a.stamps) tstamp[0] = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const RowGeom& g = a.g;
   const int tpp = g.Rp / BN;
-  // the row groups of one column tile (same B tile, streamed over the whole K) are consecutive workgroups of one XCD:
-  // the tile comes out of HBM once instead of once per row group (the K = 49152 cond_layer dgrad has five)
   const unsigned wgid = xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int by = (int)(wgid % gridDim.y), tile = (int)(wgid / gridDim.y);
   const int p = tile / tpp, r0 = (tile - p * tpp) * BN;
-  // A residual launch can carry the folded end x skip GEMM as one extra row group (same B operand: the acts planes;
-  // 32-row matrix a.A_es, epilogue of EPI_ES) instead of a launch of its own.
-  const bool es_group = (EPI == EPI_RES) && a.A_es != nullptr && by == (int)gridDim.y - 1;
-  const int blk = es_group ? w : by * PG_WAVES + w;
-  const bool active = blk * 32 < (es_group ? 32 : a.M);
   const size_t R64 = (size_t)g.R * 64;
 
-  const _Float16* Ap = (es_group ? a.A_es : a.A) + (size_t)p * a.a_phase_stride;
-  const int ablk = active ? blk : 0;
-  const size_t a_step = (size_t)(es_group ? 1 : a.n_blk) * 2048;   // elements per K-step: blocks x 4 sub-steps x 64 lanes x 8
+  // 32-row blocks of this wave; blocks past the matrix run the same instruction stream on block 0, nothing stored
+  const _Float16* Ap = a.A + (size_t)p * a.a_phase_stride;
+  const size_t a_step = (size_t)a.n_blk * 2048;   // elements per K-step: blocks x 4 sub-steps x 64 lanes x 8
+  int blk[MT];
   const _Float16* arow[MT];
-  arow[0] = Ap + (size_t)ablk * 2048 + lane * 8;
-  if (MT == 2) arow[MT - 1] = Ap + (size_t)(a.M / 32 + ablk) * 2048 + lane * 8;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    blk[mt] = (by * MT + mt) * PG_WAVES + w;
+    arow[mt] = Ap + (size_t)(blk[mt] * 32 < a.M ? blk[mt] : 0) * 2048 + lane * 8;
+  }
 
   f32x16 acc[MT][CT];
 #pragma unroll
@@ -154,9 +148,7 @@ plane_gemm_kernel(const PGemmArgs a) {
   fetch_a(aring[1], last < 1 ? last : 1);
   commit_b(0, bst[0]);
   __syncthreads();
-  if (EPI == EPI_GATE && a.stamps) tstamp[1] = __builtin_amdgcn_s_memtime();
 
-  // waves without rows (M < 256 x MT) run the same instruction stream on block 0 and skip the epilogue
   auto body = [&](auto PAR, int st) {
     constexpr int par = decltype(PAR)::value;    // = st & 1: ring slot, B stage and LDS buffer of this step
     const int st2 = st + 2 < last ? st + 2 : last;
@@ -195,107 +187,33 @@ plane_gemm_kernel(const PGemmArgs a) {
     body(std::integral_constant<int, 1>{}, st + 1);
   }
   if (st < n_steps) body(std::integral_constant<int, 0>{}, st);
-  if (EPI == EPI_GATE && a.stamps) tstamp[2] = __builtin_amdgcn_s_memtime();
-  if (!active) return;
 
-  // ---- epilogue: lane (column r of column tile ct, half h) holds matrix positions P0 .. P0+15 of its 32-block
-  const int P0 = blk * 32 + 16 * h;
+  // ---- epilogue: lane (column r of column tile ct, half h) holds matrix positions P0 .. P0+15 of each of its 32-blocks
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    const int rr = r0 + ct * 32 + r;
-    int b, t;
-    const bool valid = column_valid(g, p, rr, b, t);
-    const size_t prow = (size_t)kRowPad + (size_t)p * g.Rp + rr;
-    const size_t addr = ((size_t)(P0 >> 6) * g.R + prow) * 64 + (P0 & 63);
-    if (EPI == EPI_GATE) {
-      half8 T0, T1, S0, S1, A0, A1;
+  for (int mt = 0; mt < MT; ++mt) {
+    if (blk[mt] * 32 >= a.M) continue;
+    const int P0 = blk[mt] * 32 + 16 * h;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float u = acc[0][ct][j] + a.bias[P0 + j];
-        const float v = acc[MT - 1][ct][j] + a.bias[a.M + P0 + j];
-        // tanh(u) = 1 - 2/(1 + e^{2u}),  sigmoid(v) = 1/(1 + e^{-v})            (model.py:17-18)
-        float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
-        float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
-        if (!valid) { th = 0.0f; sg = 0.0f; }
-        const _Float16 th16 = (_Float16)th, sg16 = (_Float16)sg;
-        // acts from the ROUNDED factors: the backward pass sees exactly the saved T and S
-        const _Float16 ac16 = (_Float16)((float)th16 * (float)sg16);
-        if (j < 8) { T0[j] = th16; S0[j] = sg16; A0[j] = ac16; }
-        else { T1[j - 8] = th16; S1[j - 8] = sg16; A1[j - 8] = ac16; }
-      }
-      *(half8*)(a.o0 + addr) = T0; *(half8*)(a.o0 + addr + 8) = T1;
-      *(half8*)(a.o1 + addr) = S0; *(half8*)(a.o1 + addr + 8) = S1;
-      *(half8*)(a.o2 + addr) = A0; *(half8*)(a.o2 + addr + 8) = A1;
-    } else if (EPI == EPI_RES && es_group) {
-      if (blk == 0 && valid) {               // same code as EPI_ES below
-        float4* op = (float4*)(a.rows32 + ((size_t)b * g.L + t) * 8 + 4 * h);
-        float4 o = *op;
-        o.x += acc[0][ct][0] + acc[0][ct][4];
-        o.y += acc[0][ct][1] + acc[0][ct][5];
-        o.z += acc[0][ct][2] + acc[0][ct][6];
-        o.w += acc[0][ct][3] + acc[0][ct][7];
-        *op = o;
-      }
-    } else if (EPI == EPI_RES) {
-      half8 in0, in1, o0, o1;
-      if (a.i0) { in0 = *(const half8*)(a.i0 + addr); in1 = *(const half8*)(a.i0 + addr + 8); }
+    for (int ct = 0; ct < CT; ++ct) {
+      const int rr = r0 + ct * 32 + r;
+      int b, t;
+      const bool valid = column_valid(g, p, rr, b, t);
+      const size_t prow = (size_t)kRowPad + (size_t)p * g.Rp + rr;
+      const size_t addr = ((size_t)(P0 >> 6) * g.R + prow) * 64 + (P0 & 63);
+      half8 o0, o1;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        float v = acc[0][ct][j];
+        float v = acc[mt][ct][j];
         if (a.bias) v += a.bias[P0 + j];
-        if (a.i0) v += (float)(j < 8 ? in0[j & 7] : in1[j & 7]);
         if (!valid) v = 0.0f;
         if (j < 8) o0[j] = (_Float16)v; else o1[j - 8] = (_Float16)v;
       }
       *(half8*)(a.o0 + addr) = o0; *(half8*)(a.o0 + addr + 8) = o1;
-    } else if (EPI == EPI_ES) {
-      // matrix rows (natural order) 0-7 = hi, 8-15 = lo halves of the folded end x skip rows: MFMA row
-      // 8(j>>2) + 4h + (j&3), so lane half h holds output channels 4h .. 4h+3 as acc[i] (hi) + acc[4+i] (lo)
-      if (blk == 0 && valid) {
-        float4* op = (float4*)(a.rows32 + ((size_t)b * g.L + t) * 8 + 4 * h);
-        float4 o = *op;
-        o.x += acc[0][ct][0] + acc[0][ct][4];
-        o.y += acc[0][ct][1] + acc[0][ct][5];
-        o.z += acc[0][ct][2] + acc[0][ct][6];
-        o.w += acc[0][ct][3] + acc[0][ct][7];
-        *op = o;
-      }
-    } else if (EPI == EPI_DGATE) {
-      const half8 T0 = *(const half8*)(a.i0 + addr), T1 = *(const half8*)(a.i0 + addr + 8);
-      const half8 S0 = *(const half8*)(a.i1 + addr), S1 = *(const half8*)(a.i1 + addr + 8);
-      half8 gt0, gt1, gs0, gs1;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float th = (float)(j < 8 ? T0[j & 7] : T1[j & 7]);
-        const float sg = (float)(j < 8 ? S0[j & 7] : S1[j & 7]);
-        const float ga = valid ? acc[0][ct][j] : 0.0f;
-        const float gt = ga * sg * (1.0f - th * th);      // d/du tanh(u) sigmoid(v)
-        const float gs = ga * th * sg * (1.0f - sg);      // d/dv
-        if (j < 8) { gt0[j] = (_Float16)gt; gs0[j] = (_Float16)gs; }
-        else { gt1[j - 8] = (_Float16)gt; gs1[j - 8] = (_Float16)gs; }
-      }
-      const int Ps = a.M + P0;
-      const size_t addr_s = ((size_t)(Ps >> 6) * g.R + prow) * 64 + (Ps & 63);
-      *(half8*)(a.o0 + addr) = gt0; *(half8*)(a.o0 + addr + 8) = gt1;
-      *(half8*)(a.o0 + addr_s) = gs0; *(half8*)(a.o0 + addr_s + 8) = gs1;
     }
-  }
-  if (EPI == EPI_GATE && a.stamps && tid == 0) {
-    tstamp[3] = __builtin_amdgcn_s_memtime();
-    unsigned long long* o = a.stamps + ((size_t)by * gridDim.x + tile) * 4;
-    o[0] = tstamp[0]; o[1] = tstamp[1]; o[2] = tstamp[2]; o[3] = tstamp[3];
   }
 }
 
 namespace {
-template <int EPI>
-void launch_pg(const PGemmArgs& a, int ct, hipStream_t s) {
-  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), (a.M + 32 * PG_WAVES - 1) / (32 * PG_WAVES) + (EPI == EPI_RES && a.A_es ? 1 : 0));
-  if (ct == 6) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 6>), grid, dim3(PG_THREADS), 0, s, a);
-  else if (ct == 4) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 4>), grid, dim3(PG_THREADS), 0, s, a);
-  else if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<EPI, 3>), grid, dim3(PG_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((plane_gemm_kernel<EPI, 2>), grid, dim3(PG_THREADS), 0, s, a);
-}
 int device_cus() {
   static int n = 0;
   if (!n) {
@@ -308,13 +226,14 @@ int device_cus() {
 }
 }  // namespace
 
-// Tile width: one workgroup per CU (4 waves x up to 512 registers), so a launch runs in ceil(workgroups / CUs)
-// rounds; among the widths that divide Rp pick the one with the least rounds x width, wider first (config 4, 256
-// channels: Rp = 2304 -> 384 tiles of 192 columns x 2 row groups = 768 workgroups = exactly 3 rounds on 256 CUs).
-int plane_gemm_tile_cols(const RowGeom& g, int m_groups) {
+// Tile width: one workgroup per CU, so a launch runs in ceil(workgroups / CUs) rounds; among the widths that divide Rp
+// (and fit the registers: MT x CT accumulator tiles of 16 registers) pick the one with the least rounds x width, wider
+// first (config 4, M = 640 as one row group: Rp = 2304 -> 768 tiles of 96 columns = exactly 3 rounds on 256 CUs).
+int plane_gemm_tile_cols(const RowGeom& g, int m_groups, int mt) {
+  const int max_ct = mt >= 5 ? 3 : 6;
   if (const char* e = getenv("WG_TRAIN_CT")) {      // tests: pin the tile width (2, 3, 4 or 6 column tiles of 32)
     const int ct = atoi(e);
-    if ((ct == 2 || ct == 3 || ct == 4 || ct == 6) && g.Rp % (32 * ct) == 0) return ct;
+    if ((ct == 2 || ct == 3 || ct == 4 || ct == 6) && ct <= max_ct && g.Rp % (32 * ct) == 0) return ct;
   }
   const int cus = device_cus();
   static const int widths[4] = {6, 4, 3, 2};
@@ -322,32 +241,34 @@ int plane_gemm_tile_cols(const RowGeom& g, int m_groups) {
   long long best_cost = 0;
   for (int i = 0; i < 4; ++i) {
     const int ct = widths[i];
-    if (g.Rp % (32 * ct)) continue;
+    if (ct > max_ct || g.Rp % (32 * ct)) continue;
     const long long wgs = (long long)kPhases * (g.Rp / (32 * ct)) * m_groups;
     // rounds x width, plus 2.5 % per dropped column tile: a narrower tile re-reads the weights more often from L2
-    // (the K = 49152 cond_layer dgrad at 96 columns pulled 48 GB through L2 per launch)
     const long long cost = ((wgs + cus - 1) / cus) * ct * (1000 + 25 * (6 - ct));
     if (!best || cost < best_cost) { best = ct; best_cost = cost; }
   }
   return best;
 }
 
-hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s) {
-  if (a.g.Rp % 128 || a.n_runs < 1 || a.n_runs > kMaxRuns || a.M < 1) return hipErrorInvalidValue;
+hipError_t launch_plane_gemm(const PGemmArgs& a, hipStream_t s) {
+  if (a.g.Rp % 128 || a.n_runs < 1 || a.n_runs > kMaxRuns || a.M < 1 || !a.o0) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks * 64;
   if (k != a.ktot) return hipErrorInvalidValue;
-  const int ct = plane_gemm_tile_cols(a.g, (a.M + 32 * PG_WAVES - 1) / (32 * PG_WAVES));
-  PGemmArgs b = a;
-  b.stamps = g_pg_stamps;
-  switch (epi) {
-    case EPI_STORE16:
-    case EPI_RES: launch_pg<EPI_RES>(b, ct, s); break;
-    case EPI_GATE: launch_pg<EPI_GATE>(b, ct, s); break;
-    case EPI_ES: launch_pg<EPI_ES>(b, ct, s); break;
-    case EPI_DGATE: launch_pg<EPI_DGATE>(b, ct, s); break;
-    default: return hipErrorInvalidValue;
-  }
+  // all rows in one workgroup when they are 5 x 128 (80 mel channels x 8); WG_TRAIN_MT=1 (tests, A/B): 128-row groups
+  int mt = (a.M == 5 * 32 * PG_WAVES) ? 5 : 1;
+  if (const char* e = getenv("WG_TRAIN_MT"))
+    if (atoi(e) == 1) mt = 1;
+  const int m_groups = (a.M + 32 * PG_WAVES * mt - 1) / (32 * PG_WAVES * mt);
+  const int ct = plane_gemm_tile_cols(a.g, m_groups, mt);
+  dim3 grid(kPhases * (a.g.Rp / (32 * ct)), m_groups);
+  if (mt == 5) {
+    if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<3, 5>), grid, dim3(PG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((plane_gemm_kernel<2, 5>), grid, dim3(PG_THREADS), 0, s, a);
+  } else if (ct == 6) hipLaunchKernelGGL((plane_gemm_kernel<6, 1>), grid, dim3(PG_THREADS), 0, s, a);
+  else if (ct == 4) hipLaunchKernelGGL((plane_gemm_kernel<4, 1>), grid, dim3(PG_THREADS), 0, s, a);
+  else if (ct == 3) hipLaunchKernelGGL((plane_gemm_kernel<3, 1>), grid, dim3(PG_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((plane_gemm_kernel<2, 1>), grid, dim3(PG_THREADS), 0, s, a);
   return hipGetLastError();
 }
 

@@ -233,12 +233,6 @@ PRun run_of(const _Float16* base, int n_chunks, int dt) {
 
 extern "C" {
 
-/* diagnostics (not in the public header): device buffer for the gate GEMM's phase stamps, see tools/stamp_train.py */
-int wg_train_debug_stamps(void* device_buffer) {
-  set_plane_gemm_stamps((unsigned long long*)device_buffer);
-  return WG_OK;
-}
-
 int32_t wg_wn_waves(int32_t n_channels) { return wn_waves(n_channels); }
 
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
@@ -297,7 +291,7 @@ int wg_train_forward(wg_handle* h, const wg_train_weights* wt, const void* mel, 
     a.bias = wt->bup;
     a.g = g;
     a.o0 = w.SP;
-    TR_TRY(launch_plane_gemm(a, EPI_STORE16, s));
+    TR_TRY(launch_plane_gemm(a, s));
   }
   int z_ch = 0;
   for (int k = 0; k <= c.n_flows; ++k) {
@@ -670,7 +664,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.M = M8;
     a.g = g;
     a.o0 = w.GSP;
-    TR_TRY(launch_plane_gemm(a, EPI_STORE16, s));
+    TR_TRY(launch_plane_gemm(a, s));
   }
   {
     WgradArgs a;   // d upsample: per phase, d spect x mel frames q..q-3 (no sum over phases)

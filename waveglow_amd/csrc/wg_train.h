@@ -23,15 +23,8 @@ struct PRun {
 };
 constexpr int kMaxRuns = 4;
 
-enum PEpi : int {
-  EPI_STORE16 = 0,   // o0 = acc (+ bias)                                  spect planes, g_spect planes
-  EPI_GATE = 1,      // T = tanh(u), S = sigmoid(v), acts = T*S            model.py:13-20 (fp16 planes o0, o1, o2)
-  EPI_RES = 2,       // o0 = acc (+ bias) (+ i0)                           residual add model.py:131-134 / dgrad add
-  EPI_ES = 3,        // rows32[row][0..7] += acc rows (hi + lo)            folded end x skip (wg_common.h, api.cpp)
-  EPI_DGATE = 4,     // g_pre = g_acts * d(tanh*sigmoid)                   o0 = [2C] planes; i0 = T, i1 = S
-};
-
-// D[M x columns] = A[M x K] . B[K x columns]  for every 128-row tile of every phase.
+// D[M x columns] = A[M x K] . B[K x columns] (+ bias) for every column tile of every phase, stored as fp16 planes
+// (invalid columns as zeros).
 struct PGemmArgs {
   PRun run[kMaxRuns];
   int n_runs;
@@ -41,15 +34,11 @@ struct PGemmArgs {
                             // (a K offset of c chunks = A + c * n_blk * 2048)
   long long a_phase_stride; // elements added to A per phase (upsample: one matrix per phase), else 0
   int ktot;                 // sum of n_chunks * 64
-  int n_blk;                // 32-row blocks of the whole matrix (gate: 2C/32)
-  int M;                    // EPI_GATE: C (rows per gate half, matrix has 2C rows); else number of matrix rows
+  int n_blk;                // 32-row blocks of the whole matrix
+  int M;                    // number of matrix rows
   const float* bias;        // fp32, pos order, or null
   RowGeom g;
-  _Float16 *o0, *o1, *o2;   // output planes
-  const _Float16 *i0, *i1;  // epilogue input planes
-  float* rows32;            // EPI_ES: OUT [B*L][8]
-  const _Float16* A_es;     // EPI_RES only, optional: 32-row end x skip matrix run as an extra row group (rows32 set)
-  unsigned long long* stamps;   // diagnostics only (set by the launcher from set_plane_gemm_stamps), else null
+  _Float16* o0;             // output planes [M/64][R][64]
 };
 
 // dW[m][k'] = sum over the rows of one slab of G[row][m] * X[row(+shift)][k']  -> out[slab][m][k'] * out_scale
@@ -107,8 +96,7 @@ struct StartWgradArgs {
   float* partial;           // [n_workgroups][5][C]: j < 4: d Wstart[:, j], j = 4: d bstart
 };
 
-hipError_t launch_plane_gemm(const PGemmArgs& a, int epi, hipStream_t s);
-void set_plane_gemm_stamps(unsigned long long* device_buffer);   // diagnostics: [workgroups][4] s_memtime of the gate GEMM
+hipError_t launch_plane_gemm(const PGemmArgs& a, hipStream_t s);
 // one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle
 hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
