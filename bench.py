@@ -166,7 +166,7 @@ def bench_train(args, rank, world, dev, dist):
   g = torch.Generator().manual_seed(5 + rank)
   wav = (torch.rand(B, S, generator=g) * 0.6 - 0.3).to(dev)
   crit = WaveGlowLoss(1.0)
-  opt = torch.optim.Adam(model.parameters(), lr=1e-4)     # train.py:58-66
+  opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)     # train.py:58-66; fused as in waveglow_amd/training.py:load_optimizer
   from waveglow_amd.train import enable_data_parallel
   fused = enable_data_parallel(model)                     # all-reduce inside backward(), overlapped, when world > 1
   red = None if fused else GradientAllReducer(model.parameters())

@@ -227,6 +227,22 @@ typedef struct wg_train_grads {
 
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len);
 
+/* The stacked weight matrices in NATURAL channel order, fp32, as the caller's autograd packing produces them every step
+ * (waveglow_amd/train.py: pack_weights; reference modules: WN.in_layers / cond_layer / res_skip_layers / end,
+ * model.py:85-113, upsample model.py:145-150). */
+typedef struct wg_train_plain {
+  const float* w1;     /* [FL][2C][K1]   in_layers[i].weight as K = tap*C + c_in (tap-major), then the layer's cond_layer rows [M8] */
+  const float* w2;     /* [FL][C][C]     res rows of res_skip_layers[i] (unused for the last layer of a flow) */
+  const float* wes;    /* [FL][8][C]     W_end . W_skip_i, zero padded to 8 rows */
+  const float* wup;    /* [32][M8][512]  upsample per phase: row (o,g), K = [tap j][128]: W_up[i][o][8p+g+256j] */
+} wg_train_plain;
+
+/* Fills the fp16 fragment tensors a1, a1c, a2, es, wat, wbt, wct, wup of *out (device buffers of the sizes documented on
+ * wg_train_weights; its other members are not touched) from the natural-order matrices: the permutations, transposes,
+ * gate pre-scales and fragment orders above in one pass per tensor.  Not differentiable -- the gradients come back in
+ * natural order (wg_train_grads).  Enqueue-only. */
+int wg_train_pack(wg_handle* h, const wg_train_plain* in, const wg_train_weights* out, void* stream);
+
 /* Waves per workgroup of the WN-layer kernel for n_channels (the NW of the fragment orders above); 0 = unsupported. */
 int32_t wg_wn_waves(int32_t n_channels);
 

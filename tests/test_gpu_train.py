@@ -392,3 +392,41 @@ def test_custom_grad_scale_and_finite_check(monkeypatch):
   model.zero_grad()
   with pytest.raises(WgError):
     WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
+
+
+@pytest.mark.parametrize("channels", [64, 256])
+def test_pack_kernel_matches_documented_fragment_orders(channels):
+  """wg_train_pack (one pass per tensor on the device) against the same layouts written as torch index arithmetic
+  (waveglow_amd/train.py: wn_forward_fragments, plain_fragments, to_fragments -- pinned element by element to the header's
+  index maps in tests/test_host_cpu.py): bit-identical fp16 tensors."""
+  from waveglow_amd import train as T
+  hp = HParams(n_channels=channels, n_layers=3, n_flows=2, n_early_every=1, n_early_size=2)
+  sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=21))
+  model = WaveGlow(hp)
+  model.load_state_dict(sd)
+  model = model.to("cuda:0").train()
+  eng = model._get_engine(torch.device("cuda:0"), need_weights=False)
+  NW = int(eng.lib.wg_wn_waves(channels))
+  with torch.no_grad():
+    packed = [t.detach() for t in T.pack_weights(model)]
+    w = T._Weights(model, packed, model.flow_channels(), NW, eng, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    Cc, M8 = channels, hp.n_mel_channels * 8
+    pm = T._perms(Cc, M8, packed[0].device)
+    a1, a1c, b1s, a2, es = T.wn_forward_fragments(packed[0], packed[1], packed[2], packed[4], pm, NW)
+    FL = packed[0].shape[0]
+    w1h = packed[0].half()
+    w1c = w1h[:, :, 3 * Cc:].index_select(1, pm.c2).index_select(2, pm.m8)
+    wat_m = torch.cat([packed[2].transpose(1, 2).index_select(2, pm.c),
+                       torch.nn.functional.pad(packed[4].half().float(), (0, 0, 0, 56)).transpose(1, 2)], 2)
+    want = {"a1": a1, "a1c": a1c, "a2": a2, "es": es,
+            "wat": T.plain_fragments(wat_m.half(), NW),
+            "wbt": T.plain_fragments(torch.cat([w1h[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2).index_select(2, pm.c2)
+                                                for t in range(3)], 2), NW),
+            "wct": T.to_fragments(w1c.permute(2, 0, 1).reshape(-1, FL * 2 * Cc), pm.c2p),
+            "wup": T.to_fragments(packed[5].index_select(1, pm.m8).half(), pm.c2p)}
+    for name, t in want.items():
+      got = getattr(w, name)
+      assert got.numel() == t.numel(), name
+      assert torch.equal(got.view(-1).view(torch.int16), t.reshape(-1).view(torch.int16)), name
+    assert torch.equal(w.b1, b1s)

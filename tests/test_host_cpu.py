@@ -388,3 +388,25 @@ def test_wn_kernel_fragment_orders():
   for (f, ks, u1, w, mb, k2, lane, j) in [(0, 0, 0, 0, 0, 0, 0, 0), (1, 1, 1, 1, 0, 1, 50, 3)]:
     r, hh = lane & 31, lane >> 5
     assert pf[f, ks, u1, w, mb, k2, lane, j] == mat[f, 32 * (w * MB + mb) + r, 64 * ks + 32 * u1 + 16 * k2 + 8 * hh + j]
+
+
+def test_batched_log_det_w_equals_per_flow_logdet():
+  """waveglow_amd/train.py:_log_det_w pads every flow's 1x1 weight into an 8x8 identity and takes ONE batched logdet;
+  values and gradients must equal the reference's per-flow ``B * L * torch.logdet(W)`` (model.py:63)."""
+  import torch
+  from waveglow_amd.hparams import HParams
+  from waveglow_amd.model import WaveGlow
+  from waveglow_amd.train import _log_det_w
+  torch.manual_seed(3)
+  model = WaveGlow(HParams(n_channels=64, n_layers=2))
+  n = 7 * 125
+  got = _log_det_w(model, n)
+  assert len(got) == model.n_flows and all(t.dim() == 0 for t in got)
+  want = [n * torch.logdet(model.convinv[k].conv.weight.squeeze()) for k in range(model.n_flows)]
+  for k in range(model.n_flows):
+    assert torch.allclose(got[k], want[k], rtol=1e-6, atol=1e-4), k
+  coef = torch.linspace(0.5, 1.5, model.n_flows)
+  g_got = torch.autograd.grad(sum(c * t for c, t in zip(coef, got)), [m.conv.weight for m in model.convinv])
+  g_want = torch.autograd.grad(sum(c * t for c, t in zip(coef, want)), [m.conv.weight for m in model.convinv])
+  for a, b in zip(g_got, g_want):
+    assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))

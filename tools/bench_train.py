@@ -36,7 +36,7 @@ def main():
   g = torch.Generator().manual_seed(3)
   wav = (torch.rand(a.batch, a.segment, generator=g) * 0.6 - 0.3).cuda()
   crit = WaveGlowLoss(1.0)
-  opt = torch.optim.Adam(model.parameters(), lr=1e-4) if a.adam else None
+  opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True) if a.adam else None
   ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
   t_f = t_b = t_o = 0.0
   wall = 0.0

@@ -27,6 +27,11 @@ class WgTrainWeights(C.Structure):
     "a1", "a1c", "b1", "a2", "b2", "es", "wat", "wbt", "wct", "wup", "bup", "wstart", "bstart", "out_init", "w1x1")]
 
 
+class WgTrainPlain(C.Structure):
+  """wg_train_plain: the natural-order fp32 matrices wg_train_pack reads."""
+  _fields_ = [(n, C.c_void_p) for n in ("w1", "w2", "wes", "wup")]
+
+
 class WgTrainGrads(C.Structure):
   """wg_train_grads: device pointers; the last three are arrays of n_flows pointers."""
   _fields_ = [(n, C.c_void_p) for n in (
@@ -65,6 +70,7 @@ SIGNATURES = {
   "wg_macs_per_group_step": (C.c_double, [C.c_void_p]),
   "wg_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
   "wg_wn_waves": (C.c_int32, [C.c_int32]),
+  "wg_train_pack": (C.c_int, [C.c_void_p, C.POINTER(WgTrainPlain), C.POINTER(WgTrainWeights), C.c_void_p]),
   "wg_train_forward": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),

@@ -510,6 +510,134 @@ hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s) {
   return hipGetLastError();
 }
 
+// =============================================================================================
+// Weight packing (wg_train_pack): natural-order fp32 matrices -> the fp16 MFMA-fragment tensors of wg_train_weights,
+// one pass per tensor, one thread per 16-byte output piece (8 consecutive K positions of one row).  Position order is
+// a permutation inside 32-blocks (wg_common.h: pos_to_chan): positions p0 .. p0+7 of a block (p0 = 0, 8, 16, 24) are
+// natural channels n0 .. n0+3 and n0+8 .. n0+11 with n0 = 16*((p0>>3)&1) + 4*(p0>>4) -- two runs of four.
+// =============================================================================================
+namespace {
+__device__ __forceinline__ int nat0_of(int p0) { return 16 * ((p0 >> 3) & 1) + 4 * (p0 >> 4); }   // p0 in {0, 8, 16, 24}
+__device__ __forceinline__ half8 cvt8(const float4 lo, const float4 hi, float sc) {
+  half8 o;
+  o[0] = (_Float16)(lo.x * sc); o[1] = (_Float16)(lo.y * sc); o[2] = (_Float16)(lo.z * sc); o[3] = (_Float16)(lo.w * sc);
+  o[4] = (_Float16)(hi.x * sc); o[5] = (_Float16)(hi.y * sc); o[6] = (_Float16)(hi.z * sc); o[7] = (_Float16)(hi.w * sc);
+  return o;
+}
+// 8 K positions of one row that are contiguous runs in memory: row[n0 .. n0+3], row[n0+8 .. n0+11]
+__device__ __forceinline__ half8 row_runs(const float* row, int n0, float sc) {
+  return cvt8(*(const float4*)(row + n0), *(const float4*)(row + n0 + 8), sc);
+}
+// 8 K positions that are 8 ROWS of one column: rows r0 .. r0+3 and r0+8 .. r0+11 (row stride ld)
+__device__ __forceinline__ half8 col_runs(const float* col, int r0, size_t ld) {
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)col[(size_t)(r0 + (j & 3) + 2 * (j & 4)) * ld];
+  return o;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
+  const int C = a.C, M8 = a.M8, NW = a.NW, MB = C / (32 * NW), K1 = 3 * C + M8;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < a.n_pieces; q += (size_t)gridDim.x * 256) {
+    half8 o;
+    _Float16* dst = a.dst + q * 8;
+    if (a.kind == PACK_A1) {
+      // [FL][ks][u1][w][gate][mb][k2][hh][r][8]: row gate*C + 32*(w*MB + mb) + r, K position 64 ks + 32 u1 + 16 k2 + 8 hh
+      const size_t per_ks = (size_t)512 * MB * NW, per_fl = per_ks * (K1 / 64);
+      const int fl = (int)(q / per_fl);
+      size_t e = q - (size_t)fl * per_fl;
+      const int ks = (int)(e / per_ks);
+      e -= (size_t)ks * per_ks;
+      const int r = e & 31, hh = (e >> 5) & 1, k2 = (e >> 6) & 1;
+      const int mtq = (int)((e >> 7) % (2 * MB)), rest = (int)((e >> 7) / (2 * MB));
+      const int w = rest % NW, u1 = rest / NW;
+      const int gate = mtq / MB, mb = mtq - gate * MB;
+      const int m = gate * C + 32 * (w * MB + mb) + r;
+      const int n0 = 64 * ks + 32 * u1 + nat0_of(16 * k2 + 8 * hh);
+      o = row_runs(a.w1 + ((size_t)fl * 2 * C + m) * K1, n0, gate ? -1.4426950408889634f : 2.8853900817779268f);
+      const int n_tap = 3 * C / 64;
+      if (ks < n_tap) dst = a.dst + (((size_t)fl * n_tap + ks) * per_ks + e) * 8;
+      else dst = a.dst2 + (((size_t)fl * (K1 / 64 - n_tap) + (ks - n_tap)) * per_ks + e) * 8;
+    } else if (a.kind == PACK_A2) {
+      // [FL][w][mb][k16][hh][r][8]: W_res[32*(w*MB + mb) + r][position 16 k16 + 8 hh]
+      const int r = q & 31, hh = (q >> 5) & 1;
+      size_t e = q >> 6;
+      const int k16 = (int)(e % (C / 16));
+      e /= (C / 16);
+      const int blk = (int)(e % (NW * MB)), fl = (int)(e / (NW * MB));
+      const int n0 = 32 * (k16 >> 1) + nat0_of(16 * (k16 & 1) + 8 * hh);
+      o = row_runs(a.w2 + ((size_t)fl * C + 32 * blk + r) * C, n0, 1.0f);
+    } else if (a.kind == PACK_ES) {
+      // [FL][s][l4][row][8]: hi (row < 8) / lo (row >= 8) fp16 half of Wes[row & 7][position 32 s + 8 l4]
+      const int row = q & 15, l4 = (q >> 4) & 3;
+      const size_t e = q >> 6;
+      const int s_ = (int)(e % (C / 32)), fl = (int)(e / (C / 32));
+      const float* src = a.wes + ((size_t)fl * 8 + (row & 7)) * C + 32 * s_ + nat0_of(8 * l4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float full = src[(j & 3) + 2 * (j & 4)];
+        const _Float16 hi = (_Float16)full;
+        o[j] = row < 8 ? hi : (_Float16)(full - (float)hi);
+      }
+    } else if (a.kind == PACK_WAT || a.kind == PACK_WBT) {
+      // plain row blocks [FL][ks][u1][w][mb][k2][hh][r][8]: Mat[32*(w*MB + mb) + r][64 ks + 32 u1 + 16 k2 + 8 hh + j]
+      const int Kt = a.kind == PACK_WAT ? C + 64 : 6 * C;
+      const size_t per_ks = (size_t)256 * MB * NW, per_fl = per_ks * (Kt / 64);
+      const int fl = (int)(q / per_fl);
+      size_t e = q - (size_t)fl * per_fl;
+      const int ks = (int)(e / per_ks);
+      e -= (size_t)ks * per_ks;
+      const int r = e & 31, hh = (e >> 5) & 1, k2 = (e >> 6) & 1;
+      const int mb = (int)((e >> 7) % MB), rest = (int)((e >> 7) / MB);
+      const int w = rest % NW, u1 = rest / NW;
+      const int m = 32 * (w * MB + mb) + r;                      // natural channel: a column of the source matrix
+      const int k0 = 64 * ks + 32 * u1, p0 = 16 * k2 + 8 * hh;   // K position k0 + p0 + j
+      if (a.kind == PACK_WBT) {
+        // Mat = W_in[:, :, tap]^T: K = tap * 2C + (position of the d pre row)
+        const int tap = k0 / (2 * C), q0 = k0 - tap * 2 * C;
+        o = col_runs(a.w1 + (size_t)fl * 2 * C * K1 + tap * C + m, q0 + nat0_of(p0), (size_t)K1);
+      } else if (k0 < C) {
+        // Mat = [ W_res^T | ... ]: K = position of the d x row
+        o = col_runs(a.w2 + (size_t)fl * C * C + m, k0 + nat0_of(p0), (size_t)C);
+      } else {
+        // ... | (W_end W_skip)^T, 8 channels, padded to 64 ]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int d = k0 - C + p0 + j;
+          o[j] = d < 8 ? (_Float16)a.wes[((size_t)fl * 8 + d) * C + m] : (_Float16)0.0f;
+        }
+      }
+    } else if (a.kind == PACK_WCT) {
+      // [t][b][s][h][r][8] of Mat [M8 (pos)][FL*2C (pos)] = cond_layer^T: element = W1[fl][row nat(Q)][3C + 32 b + r]
+      const int r = q & 31, h = (q >> 5) & 1, s_ = (q >> 6) & 3;
+      const size_t e = q >> 8;
+      const int b = (int)(e % (M8 / 32));
+      const size_t t = e / (M8 / 32);
+      const size_t kc = 64 * t + 32 * h + 8 * s_;
+      const int fl = (int)(kc / (2 * C)), q0 = (int)(kc - (size_t)fl * 2 * C);
+      o = col_runs(a.w1 + (size_t)fl * 2 * C * K1 + 3 * C + 32 * b + r, (q0 & ~31) + nat0_of(q0 & 31), (size_t)K1);
+    } else {
+      // PACK_WUP [p][t][b][s][h][r][8] = Wup[p][32 b + r][64 t + 32 h + 8 s + j]   (rows natural: pos(chan_to_pos(r)) = r)
+      const int r = q & 31, h = (q >> 5) & 1, s_ = (q >> 6) & 3;
+      size_t e = q >> 8;
+      const int b = (int)(e % (M8 / 32));
+      e /= (M8 / 32);
+      const int t = (int)(e % 8), p = (int)(e / 8);
+      const float* src = a.wup + ((size_t)p * M8 + 32 * b + r) * 512 + 64 * t + 32 * h + 8 * s_;
+      o = cvt8(*(const float4*)src, *(const float4*)(src + 4), 1.0f);
+    }
+    *(half8*)dst = o;
+  }
+}
+
+hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
+  if (a.n_pieces == 0) return hipSuccess;
+  const size_t blocks = (a.n_pieces + 255) / 256;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads; a workgroup is
 // 64 float4 columns x 4 slab groups (thread (x, y) sums slabs y, y+4, ... with two independent partial sums), then the
 // four groups are combined through LDS in a fixed order -- 8 slab reads in flight per element instead of a serial chain.

@@ -235,6 +235,37 @@ extern "C" {
 
 int32_t wg_wn_waves(int32_t n_channels) { return wn_waves(n_channels); }
 
+int wg_train_pack(wg_handle* h, const wg_train_plain* in, const wg_train_weights* out, void* stream) {
+  if (!h || !in || !out) return wg_set_error(WG_ERR_INVALID, "null argument");
+  if (!in->w1 || !in->w2 || !in->wes || !in->wup || !out->a1 || !out->a1c || !out->a2 || !out->es || !out->wat ||
+      !out->wbt || !out->wct || !out->wup)
+    return wg_set_error(WG_ERR_INVALID, "wg_train_pack: null tensor");
+  const wg_config& c = *wg_internal_config(h);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.n_channels, M8 = c.n_mel_channels * 8, FL = c.n_flows * c.n_layers, NW = wn_waves(C);
+  if (NW <= 0 || M8 % 64) return wg_set_error(WG_ERR_INVALID, "wg_train_pack: unsupported channel counts");
+  const size_t K1 = 3 * (size_t)C + M8;
+  PackArgs a;
+  memset(&a, 0, sizeof a);
+  a.C = C; a.M8 = M8; a.FL = FL; a.NW = NW;
+  a.w1 = in->w1; a.w2 = in->w2; a.wes = in->wes; a.wup = in->wup;
+  auto run = [&](int kind, const void* dst, const void* dst2, size_t elements) -> hipError_t {
+    a.kind = kind;
+    a.dst = (_Float16*)const_cast<void*>(dst);
+    a.dst2 = (_Float16*)const_cast<void*>(dst2);
+    a.n_pieces = elements / 8;
+    return launch_pack(a, s);
+  };
+  TR_TRY(run(PACK_A1, out->a1, out->a1c, (size_t)FL * 2 * C * K1));
+  TR_TRY(run(PACK_A2, out->a2, nullptr, (size_t)FL * C * C));
+  TR_TRY(run(PACK_ES, out->es, nullptr, (size_t)FL * 16 * C));
+  TR_TRY(run(PACK_WAT, out->wat, nullptr, (size_t)FL * C * (C + 64)));
+  TR_TRY(run(PACK_WBT, out->wbt, nullptr, (size_t)FL * C * 6 * C));
+  TR_TRY(run(PACK_WCT, out->wct, nullptr, (size_t)M8 * FL * 2 * C));
+  TR_TRY(run(PACK_WUP, out->wup, nullptr, (size_t)32 * M8 * 512));
+  return WG_OK;
+}
+
 size_t wg_train_workspace_bytes(const wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len) {
   Ctx x;
   if (setup(const_cast<wg_handle*>(h), B, n_frames, audio_len, nullptr, 0, x) != WG_OK) return 0;

@@ -97,6 +97,17 @@ struct StartWgradArgs {
 };
 
 hipError_t launch_plane_gemm(const PGemmArgs& a, hipStream_t s);
+
+// weight packing (train.hip: pack_kernel), one launch per output tensor
+enum PackKind : int { PACK_A1 = 0, PACK_A2, PACK_ES, PACK_WAT, PACK_WBT, PACK_WCT, PACK_WUP };
+struct PackArgs {
+  int kind;
+  int C, M8, FL, NW;
+  const float *w1, *w2, *wes, *wup;   // natural-order sources (include/waveglow_amd.h: wg_train_plain)
+  _Float16 *dst, *dst2;               // PACK_A1: a1 (tap K-steps) and a1c (conditioning K-steps)
+  size_t n_pieces;                    // 16-byte output pieces
+};
+hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 // one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle
 hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n

@@ -211,36 +211,31 @@ def plain_fragments(mat: torch.Tensor, NW: int) -> torch.Tensor:
 
 
 class _Weights:
-  """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward)."""
+  """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward).  The fp16
+  fragment tensors are filled by the library itself (``wg_train_pack``: one pass per tensor); what is left here are the
+  small fp32 vectors.  ``wn_forward_fragments`` / ``plain_fragments`` / ``to_fragments`` above are the same layouts
+  written as torch index arithmetic: the tests hold the pack kernel to them bit for bit."""
 
-  def __init__(self, model, packed, flow_c: List[int], NW: int):
+  def __init__(self, model, packed, flow_c: List[int], NW: int, eng, stream):
     hp = model._hp
     Cc, nf = hp.n_channels, model.n_flows
+    M8 = hp.n_mel_channels * 8
     dev = packed[0].device
-    pm = _perms(Cc, hp.n_mel_channels * 8, dev)
+    pm = _perms(Cc, M8, dev)
     nat = [t.detach() for t in packed]
-    # forward operands: natural rows, the WN-layer kernel's fragment order
-    self.a1, self.a1c, self.b1, self.a2, self.es = wn_forward_fragments(nat[0], nat[1], nat[2], nat[4], pm, NW)
-    self.b2 = nat[3].float().contiguous()
-    # backward operands of the plane GEMM: (pos,pos) matrices in its fragment order.  Only what that kernel still
-    # multiplies is permuted -- the cond_layer slice (d spect GEMM) and the upsample filter -- not the whole of w1
-    # (two gather passes over 277 MB at 256 channels)
     FL = nat[0].shape[0]
-    c2p = pm.c2p
-    w1h = nat[0].half()                                   # one fp32 -> fp16 pass; every gather below moves fp16
-    w1c = w1h[:, :, 3 * Cc:].index_select(1, pm.c2).index_select(2, pm.m8)               # [FL, 2C pos, M8 pos]
-    wup = nat[5].index_select(1, pm.m8)
+    K1 = 3 * Cc + M8
+    h16 = lambda n: torch.empty(n, dtype=torch.float16, device=dev)
+    n_tap = 3 * Cc // 64
+    self.a1, self.a1c = h16(FL * n_tap * 64 * 2 * Cc), h16(FL * (K1 // 64 - n_tap) * 64 * 2 * Cc)
+    self.a2, self.es = h16(FL * Cc * Cc), h16(FL * 16 * Cc)
+    self.wat, self.wbt = h16(FL * Cc * (Cc + 64)), h16(FL * Cc * 6 * Cc)
+    self.wct, self.wup = h16(M8 * FL * 2 * Cc), h16(32 * M8 * 512)
+    scale = torch.cat([torch.full((Cc,), K_TANH_SCALE), torch.full((Cc,), K_SIGM_SCALE)]).to(nat[1])
+    self.b1 = (nat[1] * scale[None, :]).float().contiguous()
+    self.b2 = nat[3].float().contiguous()
     self.bup = nat[6].index_select(0, pm.m8).float()
     start5, out_init, w1x1 = nat[7].index_select(2, pm.c), nat[8], nat[9]
-    # dgrad GEMMs (WN-layer kernel, plain rows): rows natural, K in the position order of the gradient planes
-    n_w1, n_w2, n_wes = w1h, nat[2], nat[4]
-    wat_m = torch.cat([n_w2.transpose(1, 2).index_select(2, pm.c),                          # [FL, C acts, C d-x positions]
-                       torch.nn.functional.pad(n_wes.half().float(), (0, 0, 0, 56)).transpose(1, 2)], 2)   # | 64 d-out channels
-    self.wat = plain_fragments(wat_m.half(), NW)
-    self.wbt = plain_fragments(torch.cat([n_w1[:, :, t * Cc:(t + 1) * Cc].transpose(1, 2).index_select(2, pm.c2)
-                                          for t in range(3)], 2), NW)
-    self.wct = to_fragments(w1c.permute(2, 0, 1).reshape(-1, FL * 2 * Cc), c2p)
-    self.wup = to_fragments(wup.half(), c2p)
     self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
     self.bstart = [start5[k, 4].contiguous().float() for k in range(nf)]
     self.out_init = [out_init[k].contiguous().float() for k in range(nf)]
@@ -251,6 +246,10 @@ class _Weights:
                                       _ptr(self.wat), _ptr(self.wbt), _ptr(self.wct), _ptr(self.wup), _ptr(self.bup),
                                       C.cast(self._arrs[0], C.c_void_p), C.cast(self._arrs[1], C.c_void_p),
                                       C.cast(self._arrs[2], C.c_void_p), C.cast(self._arrs[3], C.c_void_p))
+    src = [nat[0].float().contiguous(), nat[2].float().contiguous(), nat[4].float().contiguous(), nat[5].float().contiguous()]
+    plain = _lib.WgTrainPlain(*[_ptr(t) for t in src])
+    _lib.check(eng.lib.wg_train_pack(eng.handle, C.byref(plain), C.byref(self.struct), C.c_void_p(stream)))
+    self._src = src                                        # alive until the pack kernels have run (stream-ordered free is fine too)
 
 
 class _SlotGuard:
@@ -400,7 +399,8 @@ class _TrainFn(torch.autograd.Function):
     NW = int(lib.wg_wn_waves(model._hp.n_channels))
     if NW <= 0:
       raise _lib.WgError(f"n_channels={model._hp.n_channels} unsupported (64, 128, 256, 512)")
-    wts = _Weights(model, packed, flow_c, NW)
+    stream = torch.cuda.current_stream(mel.device).cuda_stream
+    wts = _Weights(model, packed, flow_c, NW, eng, stream)
     z = torch.empty((B, model.n_group, L), dtype=torch.float32, device=mel.device)
     log_s = [torch.empty((B, c // 2, L), dtype=torch.float32, device=mel.device) for c in flow_c]
     nbytes = lib.wg_train_workspace_bytes(eng.handle, B, F_, S)
@@ -409,7 +409,6 @@ class _TrainFn(torch.autograd.Function):
     slot, fresh = eng.train_workspace(nbytes, (B, F_, S, nbytes))             # held until this graph's backward has run
     ws = slot["ws"]
     ls = (C.c_void_p * len(log_s))(*[t.data_ptr() for t in log_s])
-    stream = torch.cuda.current_stream(mel.device).cuda_stream
     _lib.check(lib.wg_train_forward(eng.handle, C.byref(wts.struct), _ptr(mel), _ptr(audio), _ptr(z), ls, B, F_, S,
                                     1 if fresh else 0, _ptr(ws), ws.numel(), C.c_void_p(stream)))
     ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio, ctx.guard = model, wts, ws, (B, F_, S), audio, _SlotGuard(slot)
@@ -487,5 +486,25 @@ def train_forward(model, mel: torch.Tensor, audio: torch.Tensor, grad_scale: flo
   out = _TrainFn.apply(model, mel, audio, grad_scale, *packed)
   z, log_s = out[0], list(out[1:])
   L = S // model.n_group
-  log_det = [B * L * torch.logdet(model.convinv[k].conv.weight.squeeze()) for k in range(model.n_flows)]   # model.py:63
-  return z, log_s, log_det
+  return z, log_s, _log_det_w(model, B * L)
+
+
+def _log_det_w(model, n: int) -> List[torch.Tensor]:
+  """``batch_size * n_of_groups * torch.logdet(W)`` of every flow (model.py:63) as ONE batched LU: each c_k x c_k matrix
+  sits in the top-left corner of an 8 x 8 identity (same pivots, det x 1), so the twelve flows cost the ~20 small
+  kernels of one ``logdet`` (forward and backward) instead of twelve times that -- 1.5 ms of launch latency per step at
+  config 4.  Returns the reference's list of 0-dim tensors (views of one vector)."""
+  ws = [model.convinv[k].conv.weight.squeeze(2) for k in range(model.n_flows)]
+  dev = ws[0].device
+  ng = model.n_group
+  key = (str(dev), tuple(w.shape[0] for w in ws))
+  cache = getattr(model, "_logdet_pad", None)
+  if cache is None or cache[0] != key:
+    base = torch.eye(ng, device=dev).repeat(len(ws), 1, 1)
+    idx = torch.cat([(k * ng * ng + torch.arange(c)[:, None] * ng + torch.arange(c)[None, :]).reshape(-1)
+                     for k, c in enumerate(key[1])]).to(dev)
+    cache = (key, base.reshape(-1), idx)
+    model._logdet_pad = cache
+  _, base, idx = cache
+  padded = base.index_put((idx,), torch.cat([w.reshape(-1) for w in ws])).view(len(ws), ng, ng)
+  return list((n * torch.logdet(padded)).unbind(0))
