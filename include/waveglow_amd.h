@@ -202,8 +202,8 @@ typedef struct wg_train_weights {
   const float* const* w1x1;      /* [c_k][c_k] fp32 row-major (model.py:64) */
 } wg_train_weights;
 
-/* Gradients (fp32 device buffers, same layouts as the weights they belong to; dwes is w.r.t. the effective
- * end x skip matrix [8][C], dwup w.r.t. wup's layout). */
+/* Gradients: fp32 device buffers in NATURAL channel order, w.r.t. the matrices of wg_train_plain (dw1, dw2, dwes, dwup)
+ * and the natural-order bias vectors; dwes is w.r.t. the effective end x skip matrix [8][C]. */
 typedef struct wg_train_grads {
   float* dw1;          /* [FL][2C][K1] */
   float* db1;          /* [FL][2C] */

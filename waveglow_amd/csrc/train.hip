@@ -38,6 +38,12 @@ __device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// channel stored at position P (wg_common.h: pos_to_chan): inside a 32-block, position 16h + 4g + i holds channel 8g + 4h + i
+__device__ __forceinline__ size_t pos_to_natural(size_t P) {
+  const unsigned p = (unsigned)P & 31u;
+  return (P & ~(size_t)31) + 8 * ((p >> 2) & 3u) + 4 * (p >> 4) + (p & 3u);
+}
+
 __device__ __forceinline__ bool column_valid(const RowGeom& g, int p, int rr, int& b, int& t) {
   b = rr / g.Fp;
   const int f = rr - b * g.Fp - g.Gf;
@@ -468,13 +474,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   for (int i = 0; i < 4; ++i) {
     const int m0 = (mc0 + wm) * 64 + 16 * i + 4 * g16;
     if (m0 >= Mtot) continue;
+    const int mrow = a.natural_rows ? (int)pos_to_natural((size_t)m0) : m0;     // aligned runs of four stay together
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int kk = (kc0 + wk) * 64 + 16 * k + u;
       if (kk >= Ktot) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        a.out[((size_t)slab * Mtot + m0 + j) * Ktot + kk] = acc[i][k][j] * a.out_scale;
+        a.out[((size_t)slab * Mtot + mrow + j) * Ktot + kk] = acc[i][k][j] * a.out_scale;
     }
   }
 }
@@ -641,42 +648,7 @@ hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
 // out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads; a workgroup is
 // 64 float4 columns x 4 slab groups (thread (x, y) sums slabs y, y+4, ... with two independent partial sums), then the
 // four groups are combined through LDS in a fixed order -- 8 slab reads in flight per element instead of a serial chain.
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, size_t stride,
-                                                          size_t n, float scale, float* __restrict__ out) {
-  __shared__ float4 part[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const size_t n4 = n >> 2;
-  for (size_t base = (size_t)blockIdx.x * 64; base < n4; base += (size_t)gridDim.x * 64) {
-    const size_t i = base + tx;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    if (i < n4) {
-      int k = ty;
-      for (; k + 4 < n_slabs; k += 8) {
-        const float4 u = *(const float4*)(slabs + (size_t)k * stride + 4 * i);
-        const float4 v = *(const float4*)(slabs + (size_t)(k + 4) * stride + 4 * i);
-        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
-      }
-      if (k < n_slabs) {
-        const float4 u = *(const float4*)(slabs + (size_t)k * stride + 4 * i);
-        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-      }
-    }
-    part[ty][tx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-    __syncthreads();
-    if (ty == 0 && i < n4) {
-      const float4 p0 = part[0][tx], p1 = part[1][tx], p2 = part[2][tx], p3 = part[3][tx];
-      float4 o;
-      o.x = ((p0.x + p1.x) + (p2.x + p3.x)) * scale;
-      o.y = ((p0.y + p1.y) + (p2.y + p3.y)) * scale;
-      o.z = ((p0.z + p1.z) + (p2.z + p3.z)) * scale;
-      o.w = ((p0.w + p1.w) + (p2.w + p3.w)) * scale;
-      *(float4*)(out + 4 * i) = o;
-    }
-    __syncthreads();
-  }
-}
-
+// Up to kMaxSlabSegs independent segments per launch; a segment's sums can be written in natural channel order (SlabSeg).
 struct SlabMultiArgs {
   SlabSeg seg[kMaxSlabSegs];
   unsigned first_block[kMaxSlabSegs + 1];    // blocks [first_block[i], first_block[i+1]) work on segment i
@@ -717,7 +689,14 @@ __global__ void __launch_bounds__(256) slab_reduce_multi_kernel(const SlabMultiA
       o.y = ((p0.y + p1.y) + (p2.y + p3.y)) * g.scale;
       o.z = ((p0.z + p1.z) + (p2.z + p3.z)) * g.scale;
       o.w = ((p0.w + p1.w) + (p2.w + p3.w)) * g.scale;
-      *(float4*)(g.out + 4 * i) = o;
+      size_t e = 4 * i;
+      if (g.perm) {
+        size_t m = e / (size_t)g.row_len, k = e - m * (size_t)g.row_len;
+        if (g.perm & 1) m = pos_to_natural(m);
+        if (g.perm & 2) k = pos_to_natural(k);
+        e = m * (size_t)g.row_len + k;
+      }
+      *(float4*)(g.out + e) = o;
     }
     __syncthreads();
   }
@@ -730,25 +709,18 @@ hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t
   unsigned total = 0;
   for (int i = 0; i < n_segs; ++i) {
     if ((segs[i].n & 3) || (segs[i].stride & 3) || !segs[i].slabs || !segs[i].out) return hipErrorInvalidValue;
+    if (segs[i].perm && (segs[i].row_len < 4 || (segs[i].row_len & 3) || segs[i].n % (size_t)segs[i].row_len)) return hipErrorInvalidValue;
+    if ((segs[i].perm & 2) && (segs[i].row_len & 31)) return hipErrorInvalidValue;
+    if ((segs[i].perm & 1) && ((segs[i].n / (size_t)segs[i].row_len) & 31)) return hipErrorInvalidValue;
     a.seg[i] = segs[i];
     a.first_block[i] = total;
-    size_t blocks = (segs[i].n / 4 + 63) / 64;     // same arithmetic (and summation order) as slab_reduce_kernel
+    size_t blocks = (segs[i].n / 4 + 63) / 64;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     total += (unsigned)blocks;
   }
   for (int i = n_segs; i <= kMaxSlabSegs; ++i) a.first_block[i] = total;
   hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(total), dim3(256), 0, s, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
-                              hipStream_t s) {
-  if ((n & 3) || (stride & 3)) return hipErrorInvalidValue;
-  size_t blocks = (n / 4 + 63) / 64;
-  if (blocks > 8192) blocks = 8192;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, n_slabs, stride, n, scale, out);
   return hipGetLastError();
 }
 

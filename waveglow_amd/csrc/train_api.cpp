@@ -221,6 +221,13 @@ hipError_t launch_part(WnLayerArgs a, const RowGeom& g, int bn, int part, int pa
   return launch(a, bn);
 }
 
+SlabSeg make_seg(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out, int row_len, int perm) {
+  SlabSeg g;
+  g.slabs = slabs; g.out = out; g.stride = stride; g.n = n; g.n_slabs = n_slabs; g.scale = scale;
+  g.row_len = row_len; g.perm = perm;
+  return g;
+}
+
 PRun run_of(const _Float16* base, int n_chunks, int dt) {
   PRun r;
   r.base = base;
@@ -610,20 +617,20 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         const size_t n1 = (size_t)2 * C * K1, slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
         SlabSeg seg[kMaxSlabSegs];
         int nseg = 0;
-        auto add = [&](const float* slabs, int n_slabs, size_t stride, size_t n, float* out) {
-          seg[nseg].slabs = slabs; seg[nseg].out = out; seg[nseg].stride = stride; seg[nseg].n = n;
-          seg[nseg].n_slabs = n_slabs; seg[nseg].scale = inv;
+        // (results in NATURAL channel order: perm bit 0 = rows are channels, bit 1 = columns are -- SlabSeg)
+        auto add = [&](const float* slabs, int n_slabs, size_t stride, size_t n, float* out, int row_len, int perm) {
+          seg[nseg] = make_seg(slabs, n_slabs, stride, n, inv, out, row_len, perm);
           ++nseg;
         };
-        add(w.slab, kPhases / big_pps, n1, n1, gr->dw1 + gofs(fl, n1));
-        add(w.part, kPhases / big_pps, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C));
+        add(w.slab, kPhases / big_pps, n1, n1, gr->dw1 + gofs(fl, n1), K1, 3);
+        add(w.part, kPhases / big_pps, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
         if (gx) {
-          add(w.slab2, ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C));
-          add(w.part2, ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C));
+          add(w.slab2, ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C), C, 3);
+          add(w.part2, ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
         }
-        add(w.slab2 + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C));
+        add(w.slab2 + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
         // d out_init = sum over columns of (d b | d log_s), once per flow
-        if (i == 0) add(w.part2 + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k]);
+        if (i == 0) add(w.part2 + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k], 0, 0);
         TR_TRY(launch_slab_reduce_multi(seg, nseg, sW));
         TR_ORDER(mark(sW, w_done[i]));
       }
@@ -662,7 +669,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
       a.Zpost = fb.Zpost;
       a.partial = w.part3;
       TR_TRY(launch_start_wgrad(a, s));
-      TR_TRY(launch_slab_reduce(w.part3, start_wgrad_workgroups(g), (size_t)5 * C, (size_t)5 * C, inv, gr->dstart[k], s));
+      const SlabSeg sg = make_seg(w.part3, start_wgrad_workgroups(g), (size_t)5 * C, (size_t)5 * C, inv, gr->dstart[k], C, 2);
+      TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
     }
     fb.GX = gx;
     fb.wstart = wt->wstart[k];
@@ -679,7 +687,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     }
     fb.dw_partial = w.part3;
     TR_TRY(launch_flow_bwd_post(fb, s));
-    TR_TRY(launch_slab_reduce(w.part3, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], s));
+    const SlabSeg sg = make_seg(w.part3, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], 0, 0);
+    TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }
   TR_ORDER(order_after(h, sW, s));        // every gradient of the call is final on the caller's stream
   if (flow_lo > 0) return WG_OK;          // the upsample gradient needs the d pre planes of every flow
@@ -711,8 +720,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.out = gr->dwup;
     a.out_scale = inv;
     a.bias_out = w.part;
+    a.natural_rows = 1;
     TR_TRY(launch_wgrad(a, nullptr, s));
-    TR_TRY(launch_slab_reduce(w.part, kPhases, M8, M8, inv, gr->dbup, s));
+    const SlabSeg sg = make_seg(w.part, kPhases, M8, M8, inv, gr->dbup, M8, 2);
+    TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }
   return WG_OK;
 }

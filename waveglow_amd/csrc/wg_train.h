@@ -57,6 +57,7 @@ struct WgradArgs {
   float* out;               // [32*row_split/phases_per_slab slabs][m_chunks*64][k_chunks*64] fp32
   float out_scale;
   float* bias_out;          // optional [slabs][m_chunks*64]: sum over the slab's rows of G (bias gradients), unscaled
+  int natural_rows;         // 1: `out` is a final result (no reduction follows): its rows m go to natural channel order
 };
 
 // Row kernels of the flow backward (coupling, 1x1, start): model.py:200-218 differentiated.
@@ -110,10 +111,8 @@ struct PackArgs {
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 // one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle
 hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s);
-// out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n
-hipError_t launch_slab_reduce(const float* slabs, int n_slabs, size_t stride, size_t n, float scale, float* out,
-                              hipStream_t s);
-// the same reduction for up to kMaxSlabSegs independent (slabs, out) pairs in ONE launch: a layer's weight-gradient
+// out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n  (fixed order: bitwise reproducible), for up to
+// kMaxSlabSegs independent (slabs, out) pairs in ONE launch: a layer's weight-gradient
 // launches leave six small-to-large slab sets behind, and six launches of a few microseconds each cost more in launch
 // gaps than in traffic
 constexpr int kMaxSlabSegs = 6;
@@ -123,6 +122,10 @@ struct SlabSeg {
   size_t stride, n;      // n % 4 == 0, stride % 4 == 0
   int n_slabs;
   float scale;
+  // The slabs hold [rows][row_len] in the kernels' channel-POSITION order; the sums are written in NATURAL channel order
+  // (wg_common.h: pos_to_chan, a permutation inside 32-blocks that keeps aligned runs of four together, so a float4 of
+  // positions is a float4 of channels): perm bit 0 = the rows are channels, bit 1 = the columns are.  row_len = 0: flat.
+  int row_len, perm;
 };
 hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t s);
 hipError_t launch_mel_plane(const void* mel, int io_f16, int M, const RowGeom& g, _Float16* melp, hipStream_t s);

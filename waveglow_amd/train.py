@@ -347,19 +347,12 @@ class GradBuffers:
                           C.cast(keep[2], C.c_void_p), self.rec, self.flow_stride)
     return g, keep
 
-  def packed_grads(self, pm: "_Perms") -> list:
-    """Gradients in the shapes / natural channel order of pack_weights' outputs (the inverse channel permutation is a
-    gather per tensor, which also makes the strided per-layer views dense)."""
-    nf = self.nf
-    sel = lambda t, dim, name: t.index_select(dim, getattr(pm, "i" + name))
-    dw1 = sel(sel(self.dw1, 2, "c2"), 3, "k1")
-    db1 = sel(self.db1, 2, "c2")
-    dw2 = sel(sel(self.dw2, 2, "c"), 3, "c")
-    db2 = sel(self.db2, 2, "c")
-    dwes = sel(self.dwes, 3, "c")
+  def packed_grads(self) -> list:
+    """Gradients in the shapes of pack_weights' outputs.  The library already writes them in natural channel order
+    (wg_train_grads); the per-layer views are strided, so merging the (flow, layer) axes makes them dense."""
     merge = lambda t: t.reshape(t.shape[0] * t.shape[1], *t.shape[2:])
-    return [merge(dw1), merge(db1), merge(dw2), merge(db2), merge(dwes), sel(self.dwup, 1, "m8"), sel(self.dbup, 0, "m8"),
-            sel(self.dstart, 2, "c"), self.dout_init.contiguous(), self.dw1x1.contiguous()]
+    return [merge(self.dw1), merge(self.db1), merge(self.dw2), merge(self.db2), merge(self.dwes), self.dwup, self.dbup,
+            self.dstart.contiguous(), self.dout_init.contiguous(), self.dw1x1.contiguous()]
 
 
 def flow_backward_schedule(n_flows: int, run_flow, bufs, group=None) -> None:
@@ -428,7 +421,6 @@ class _TrainFn(torch.autograd.Function):
     dev = ctx.audio.device
     nf = model.n_flows
     hp = model._hp
-    pm = _perms(hp.n_channels, hp.n_mel_channels * 8, dev)
     bufs = GradBuffers(hp.n_channels, hp.n_layers, nf, hp.n_mel_channels * 8, dev)
     gstruct, _keep = bufs.struct()
     gz = g_z.float().contiguous() if g_z is not None else None
@@ -460,7 +452,7 @@ class _TrainFn(torch.autograd.Function):
     model.grad_finite = torch.isfinite(bufs.flat).all()
     if os.environ.get("WG_TRAIN_CHECK_FINITE") == "1" and not bool(model.grad_finite):
       raise _lib.WgError(nonfinite_message(ctx.scale))
-    grads = bufs.packed_grads(pm)
+    grads = bufs.packed_grads()
     return (None, None, None, None, *grads)
 
 
