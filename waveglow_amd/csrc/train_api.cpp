@@ -100,7 +100,8 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.slab2 = (float*)take((size_t)kPhases * 4 * (C + 64) * C * 4);          // row_split 4: [128 slabs][(C/64 + 1) * 64][C]
   w.part = (float*)take((size_t)kPhases * 4 * max_sz(2 * (size_t)C, (size_t)M8) * 4);     // bias partials: [slabs][rows]
   w.part2 = (float*)take((size_t)kPhases * 4 * (C + 64) * 4);
-  w.part3 = (float*)take(max_sz((size_t)flow_bwd_workgroups(g) * 64, (size_t)start_wgrad_workgroups(g) * 5 * C) * 4);
+  w.part3 = (float*)take(max_sz(max_sz((size_t)flow_bwd_workgroups(g) * 64, (size_t)start_wgrad_workgroups(g) * 5 * C),
+                                (size_t)kPhases * M8) * 4);
   w.bytes = off;
   return w;
 }
@@ -690,8 +691,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     const SlabSeg sg = make_seg(w.part3, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], 0, 0);
     TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }
-  TR_ORDER(order_after(h, sW, s));        // every gradient of the call is final on the caller's stream
-  if (flow_lo > 0) return WG_OK;          // the upsample gradient needs the d pre planes of every flow
+  if (flow_lo > 0) {                      // the upsample gradient needs the d pre planes of every flow
+    TR_ORDER(order_after(h, sW, s));      // every gradient of the call is final on the caller's stream
+    return WG_OK;
+  }
   {
     // d spect = sum over every layer of cond_layer^T d pre: ONE GEMM with K = FL*2C over the kept d pre planes
     PGemmArgs a;
@@ -719,12 +722,13 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.phases_per_slab = 1;
     a.out = gr->dwup;
     a.out_scale = inv;
-    a.bias_out = w.part;
     a.natural_rows = 1;
+    a.bias_out = w.part3;                 // (w.part belongs to the weight-gradient stream, still busy with the last layers)
     TR_TRY(launch_wgrad(a, nullptr, s));
-    const SlabSeg sg = make_seg(w.part, kPhases, M8, M8, inv, gr->dbup, M8, 2);
+    const SlabSeg sg = make_seg(w.part3, kPhases, M8, M8, inv, gr->dbup, M8, 2);
     TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }
+  TR_ORDER(order_after(h, sW, s));        // every gradient of the call is final on the caller's stream
   return WG_OK;
 }
 

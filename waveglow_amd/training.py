@@ -268,10 +268,12 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
       model.zero_grad()
       x, y = parse_batch(batch)
       loss = criterion(model(x), y)
-      reduced_loss = loss.item()
       loss.backward()
       if reducer is not None:
         reducer.reduce()
+      # the reference reads the loss before backward() (train.py:193-195); reading it here -- same value -- leaves ONE host
+      # sync per step, after the backward pass has been queued, instead of a GPU bubble while its ~700 launches are issued
+      reduced_loss = loss.item()
       finite = getattr(model, "grad_finite", None)      # set by the library's backward (waveglow_amd/train.py)
       if finite is not None and not bool(finite):
         from .train import nonfinite_message
