@@ -279,6 +279,103 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, hipStream_t s) {
 }
 
 // =============================================================================================
+// Slab reduction.  out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads;
+// a workgroup is 64 float4 columns x 8 slab groups (thread (x, y) sums slabs y, y+8, ... with two independent partial
+// sums), then the eight groups are combined through LDS in a fixed order.  Up to kMaxSlabSegs independent segments per
+// launch; a segment's sums can be written in natural channel order (SlabSeg).  The body runs either as a kernel of its
+// own or as the third job of a weight-gradient launch (wgrad_kernel), where its memory-bound workgroups fill slots
+// next to MFMA-bound ones.
+// =============================================================================================
+struct SlabMultiArgs {
+  SlabSeg seg[kMaxSlabSegs];
+  unsigned first_block[kMaxSlabSegs + 1];    // blocks [first_block[i], first_block[i+1]) work on segment i
+  int n_segs;
+};
+constexpr int SR_GROUPS = 8;                 // 512 threads
+
+__device__ __forceinline__ void slab_reduce_body(const SlabMultiArgs& a, unsigned block, float4 (*part)[64]) {
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSlabSegs; ++i)
+    if (i < a.n_segs && block >= a.first_block[i]) si = i;
+  const SlabSeg& g = a.seg[si];
+  const unsigned nb = a.first_block[si + 1] - a.first_block[si];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const size_t n4 = g.n >> 2;
+  for (size_t base = (size_t)(block - a.first_block[si]) * 64; base < n4; base += (size_t)nb * 64) {
+    const size_t i = base + tx;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (i < n4) {
+      int k = ty;
+      for (; k + SR_GROUPS < g.n_slabs; k += 2 * SR_GROUPS) {
+        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
+        const float4 v = *(const float4*)(g.slabs + (size_t)(k + SR_GROUPS) * g.stride + 4 * i);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+      }
+      if (k < g.n_slabs) {
+        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+      }
+    }
+    part[ty][tx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (ty == 0 && i < n4) {
+      float4 o;
+#define WG_SR_COMBINE(c) (((part[0][tx].c + part[1][tx].c) + (part[2][tx].c + part[3][tx].c)) + \
+                          ((part[4][tx].c + part[5][tx].c) + (part[6][tx].c + part[7][tx].c))) * g.scale
+      o.x = WG_SR_COMBINE(x); o.y = WG_SR_COMBINE(y); o.z = WG_SR_COMBINE(z); o.w = WG_SR_COMBINE(w);
+#undef WG_SR_COMBINE
+      size_t e = 4 * i;
+      if (g.perm) {
+        size_t m = e / (size_t)g.row_len, k = e - m * (size_t)g.row_len;
+        if (g.perm & 1) m = pos_to_natural(m);
+        if (g.perm & 2) k = pos_to_natural(k);
+        e = m * (size_t)g.row_len + k;
+      }
+      *(float4*)(g.out + e) = o;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(64 * SR_GROUPS) slab_reduce_multi_kernel(const SlabMultiArgs a) {
+  __shared__ float4 part[SR_GROUPS][64];
+  slab_reduce_body(a, blockIdx.x, part);
+}
+
+namespace {
+// fills `a` from the segments; returns the number of workgroups (0: invalid)
+unsigned plan_slab_reduce(const SlabSeg* segs, int n_segs, SlabMultiArgs& a) {
+  if (n_segs < 1 || n_segs > kMaxSlabSegs) return 0;
+  a.n_segs = n_segs;
+  unsigned total = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    if ((segs[i].n & 3) || (segs[i].stride & 3) || !segs[i].slabs || !segs[i].out) return 0;
+    if (segs[i].perm && (segs[i].row_len < 4 || (segs[i].row_len & 3) || segs[i].n % (size_t)segs[i].row_len)) return 0;
+    if ((segs[i].perm & 2) && (segs[i].row_len & 31)) return 0;
+    if ((segs[i].perm & 1) && ((segs[i].n / (size_t)segs[i].row_len) & 31)) return 0;
+    a.seg[i] = segs[i];
+    a.first_block[i] = total;
+    size_t blocks = (segs[i].n / 4 + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    total += (unsigned)blocks;
+  }
+  for (int i = n_segs; i <= kMaxSlabSegs; ++i) a.first_block[i] = total;
+  return total;
+}
+}  // namespace
+
+hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t s) {
+  SlabMultiArgs a;
+  const unsigned total = plan_slab_reduce(segs, n_segs, a);
+  if (!total) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(total), dim3(64 * SR_GROUPS), 0, s, a);
+  return hipGetLastError();
+}
+
+// =============================================================================================
 // Weight gradient.  out[slab][m][k'] = sum_rows G[row][m] X[row + shift][k'] over the rows of one slab (a phase, or
 // 1/row_split of a phase).  Workgroup = 8 waves = a 256 (m) x 128 (k') output tile; wave (wm, wk) owns a 64 x 64
 // quadrant as 4 x 4 MFMA tiles of 16 x 16.  Both operands are [row][channel] planes and the contraction runs over
@@ -328,6 +425,7 @@ __device__ __forceinline__ const char* uniform_ptr(const void* p) {
 struct WgradPair {
   WgradArgs job[2];
   unsigned nwg[2];        // workgroups of each job (the second may be 0)
+  SlabMultiArgs red;      // optional third job: a slab reduction (of the PREVIOUS layer's slabs), red.n_segs = 0: none
 };
 inline unsigned wgrad_workgroups(const WgradArgs& a) {
   return (unsigned)((a.m_chunks + 3) / 4) * (unsigned)((a.k_chunks + 1) / 2) * (unsigned)(kPhases * a.row_split / a.phases_per_slab);
@@ -338,6 +436,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   extern __shared__ __attribute__((aligned(1024))) _Float16 wg_smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wk = w & 1;
+  if (blockIdx.x >= pr.nwg[0] + pr.nwg[1]) {        // third job: memory-bound, dispatched last, fills the tail
+    slab_reduce_body(pr.red, blockIdx.x - pr.nwg[0] - pr.nwg[1], (float4 (*)[64])wg_smem);
+    return;
+  }
   const bool second = blockIdx.x >= pr.nwg[0];
   const WgradArgs& a = second ? pr.job[1] : pr.job[0];
   const RowGeom& g = a.g;
@@ -497,8 +599,9 @@ hipError_t check_wgrad(const WgradArgs& a) {
 }
 }  // namespace
 
-// `b` (optional) rides in the same launch, behind `a`: put the job with the longer workgroups first
-hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s) {
+// `b` (optional) rides in the same launch, behind `a`: put the job with the longer workgroups first; `red` (optional,
+// n_red segments) is a slab reduction that rides behind both -- of slabs that an EARLIER launch on the stream wrote
+hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, const SlabSeg* red, int n_red, hipStream_t s) {
   hipError_t e = check_wgrad(a);
   if (e == hipSuccess && b) e = check_wgrad(*b);
   if (e != hipSuccess) return e;
@@ -513,7 +616,13 @@ hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s) {
   pr.job[1] = b ? *b : a;
   pr.nwg[0] = wgrad_workgroups(a);
   pr.nwg[1] = b ? wgrad_workgroups(*b) : 0u;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(pr.nwg[0] + pr.nwg[1]), dim3(512), WD_LDS_BYTES, s, pr);
+  unsigned n_red_wg = 0;
+  pr.red.n_segs = 0;
+  if (red && n_red > 0) {
+    n_red_wg = plan_slab_reduce(red, n_red, pr.red);
+    if (!n_red_wg) return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(pr.nwg[0] + pr.nwg[1] + n_red_wg), dim3(512), WD_LDS_BYTES, s, pr);
   return hipGetLastError();
 }
 
@@ -642,85 +751,6 @@ hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
   if (a.n_pieces == 0) return hipSuccess;
   const size_t blocks = (a.n_pieces + 255) / 256;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, a);
-  return hipGetLastError();
-}
-
-// out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads; a workgroup is
-// 64 float4 columns x 4 slab groups (thread (x, y) sums slabs y, y+4, ... with two independent partial sums), then the
-// four groups are combined through LDS in a fixed order -- 8 slab reads in flight per element instead of a serial chain.
-// Up to kMaxSlabSegs independent segments per launch; a segment's sums can be written in natural channel order (SlabSeg).
-struct SlabMultiArgs {
-  SlabSeg seg[kMaxSlabSegs];
-  unsigned first_block[kMaxSlabSegs + 1];    // blocks [first_block[i], first_block[i+1]) work on segment i
-  int n_segs;
-};
-__global__ void __launch_bounds__(256) slab_reduce_multi_kernel(const SlabMultiArgs a) {
-  __shared__ float4 part[4][64];
-  int si = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxSlabSegs; ++i)
-    if (i < a.n_segs && blockIdx.x >= a.first_block[i]) si = i;
-  const SlabSeg& g = a.seg[si];
-  const unsigned nb = a.first_block[si + 1] - a.first_block[si];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const size_t n4 = g.n >> 2;
-  for (size_t base = (size_t)(blockIdx.x - a.first_block[si]) * 64; base < n4; base += (size_t)nb * 64) {
-    const size_t i = base + tx;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    if (i < n4) {
-      int k = ty;
-      for (; k + 4 < g.n_slabs; k += 8) {
-        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
-        const float4 v = *(const float4*)(g.slabs + (size_t)(k + 4) * g.stride + 4 * i);
-        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
-      }
-      if (k < g.n_slabs) {
-        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
-        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-      }
-    }
-    part[ty][tx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-    __syncthreads();
-    if (ty == 0 && i < n4) {
-      const float4 p0 = part[0][tx], p1 = part[1][tx], p2 = part[2][tx], p3 = part[3][tx];
-      float4 o;
-      o.x = ((p0.x + p1.x) + (p2.x + p3.x)) * g.scale;
-      o.y = ((p0.y + p1.y) + (p2.y + p3.y)) * g.scale;
-      o.z = ((p0.z + p1.z) + (p2.z + p3.z)) * g.scale;
-      o.w = ((p0.w + p1.w) + (p2.w + p3.w)) * g.scale;
-      size_t e = 4 * i;
-      if (g.perm) {
-        size_t m = e / (size_t)g.row_len, k = e - m * (size_t)g.row_len;
-        if (g.perm & 1) m = pos_to_natural(m);
-        if (g.perm & 2) k = pos_to_natural(k);
-        e = m * (size_t)g.row_len + k;
-      }
-      *(float4*)(g.out + e) = o;
-    }
-    __syncthreads();
-  }
-}
-
-hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t s) {
-  if (n_segs < 1 || n_segs > kMaxSlabSegs) return hipErrorInvalidValue;
-  SlabMultiArgs a;
-  a.n_segs = n_segs;
-  unsigned total = 0;
-  for (int i = 0; i < n_segs; ++i) {
-    if ((segs[i].n & 3) || (segs[i].stride & 3) || !segs[i].slabs || !segs[i].out) return hipErrorInvalidValue;
-    if (segs[i].perm && (segs[i].row_len < 4 || (segs[i].row_len & 3) || segs[i].n % (size_t)segs[i].row_len)) return hipErrorInvalidValue;
-    if ((segs[i].perm & 2) && (segs[i].row_len & 31)) return hipErrorInvalidValue;
-    if ((segs[i].perm & 1) && ((segs[i].n / (size_t)segs[i].row_len) & 31)) return hipErrorInvalidValue;
-    a.seg[i] = segs[i];
-    a.first_block[i] = total;
-    size_t blocks = (segs[i].n / 4 + 63) / 64;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    total += (unsigned)blocks;
-  }
-  for (int i = n_segs; i <= kMaxSlabSegs; ++i) a.first_block[i] = total;
-  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(total), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

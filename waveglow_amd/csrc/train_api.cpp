@@ -64,8 +64,8 @@ struct TrainWs {
   _Float16 *GO[2], *SP, *MELP, *GSP;   // d out plane (per flow parity), spectrogram planes, mel planes, d spect planes
   float *Zpost, *OUT;           // [n_flows][B*L*8]
   float *GZ;                    // [B*L*8]
-  float *slab, *slab2;          // wgrad phase slabs (dW1 | dW2 + end x skip: both alive until the layer's one reduction launch)
-  float *part, *part2, *part3;  // column-sum partials of the two weight-gradient jobs / of the row kernels of a flow
+  float *slab[2], *slab2[2];    // wgrad slabs (dW1 | dW2 + end x skip), two sets: a layer's slabs are reduced inside the NEXT layer's launch
+  float *part[2], *part2[2], *part3;  // column-sum partials of the two weight-gradient jobs (two sets) / of the row kernels of a flow
   size_t plane_c;               // elements of one C-channel plane set
   size_t rows8;                 // B*L*8
   size_t zero_bytes;            // prefix that `fresh` clears (all planes)
@@ -96,10 +96,12 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.OUT = (float*)take((size_t)c.n_flows * w.rows8 * 4);
   w.GZ = (float*)take(w.rows8 * 4);
   const size_t K1 = 3 * (size_t)C + M8;
-  w.slab = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
-  w.slab2 = (float*)take((size_t)kPhases * 4 * (C + 64) * C * 4);          // row_split 4: [128 slabs][(C/64 + 1) * 64][C]
-  w.part = (float*)take((size_t)kPhases * 4 * max_sz(2 * (size_t)C, (size_t)M8) * 4);     // bias partials: [slabs][rows]
-  w.part2 = (float*)take((size_t)kPhases * 4 * (C + 64) * 4);
+  for (int q = 0; q < 2; ++q) {
+    w.slab[q] = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
+    w.slab2[q] = (float*)take((size_t)kPhases * 4 * (C + 64) * C * 4);          // row_split 4: [128 slabs][(C/64 + 1) * 64][C]
+    w.part[q] = (float*)take((size_t)kPhases * 4 * 2 * (size_t)C * 4);            // bias partials: [slabs][rows]
+    w.part2[q] = (float*)take((size_t)kPhases * 4 * (C + 64) * 4);
+  }
   w.part3 = (float*)take(max_sz(max_sz((size_t)flow_bwd_workgroups(g) * 64, (size_t)start_wgrad_workgroups(g) * 5 * C),
                                 (size_t)kPhases * M8) * 4);
   w.bytes = off;
@@ -506,6 +508,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   //                    kernel of flow k-2 waits for the last of them (w_flow[k & 1]);
   //   GP, X, T, S, A   one set per layer of the whole model: no reuse inside a call.
   TR_ORDER(order_after(h, s, sW));
+  // A layer's slabs are reduced INSIDE the next layer's weight-gradient launch (third job: its memory-bound workgroups
+  // run beside the MFMA-bound ones), from the slab set the launch before wrote; the last one gets a launch of its own.
+  SlabSeg pend[kMaxSlabSegs];
+  int n_pend = 0, n_layer = 0;
   hipEvent_t w_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, w_flow[2] = {nullptr, nullptr};
   auto mark = [&](hipStream_t st, hipEvent_t& e) -> hipError_t {
     e = nullptr;
@@ -583,6 +589,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         // job with the d out plane appended to the d x planes (the last layer has no d x: d out alone).
         // Both jobs in ONE launch: the short workgroups of the second fill the idle slots of the first one's last round.
         WgradArgs a, a2;
+        const int set = n_layer & 1;
+        ++n_layer;
         memset(&a, 0, sizeof a);
         a.G = GPi;
         a.m_chunks = 2 * cc;
@@ -595,9 +603,9 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.g = g;
         a.row_split = 1;
         a.phases_per_slab = big_pps;
-        a.out = w.slab;
+        a.out = w.slab[set];
         a.out_scale = 1.0f;
-        a.bias_out = w.part;
+        a.bias_out = w.part[set];
         memset(&a2, 0, sizeof a2);
         const int gc = gx ? cc : 0;                 // chunks of d x
         a2.G = gx ? gx : GOk;
@@ -609,30 +617,27 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a2.g = g;
         a2.row_split = small_split;
         a2.phases_per_slab = 1;
-        a2.out = w.slab2;
+        a2.out = w.slab2[set];
         a2.out_scale = 1.0f;
-        a2.bias_out = w.part2;
-        TR_PROF(sW, 6, TR_TRY(launch_wgrad(a, &a2, sW)));
-        // ONE reduction launch for everything the layer's two weight-gradient launches left in their slabs
+        a2.bias_out = w.part2[set];
+        TR_PROF(sW, 6, TR_TRY(launch_wgrad(a, &a2, n_pend ? pend : nullptr, n_pend, sW)));
+        // everything this launch left in its slabs: reduced by the next launch (or by the flush at the end of the call)
         const int ns = kPhases * small_split;
         const size_t n1 = (size_t)2 * C * K1, slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
-        SlabSeg seg[kMaxSlabSegs];
-        int nseg = 0;
+        n_pend = 0;
         // (results in NATURAL channel order: perm bit 0 = rows are channels, bit 1 = columns are -- SlabSeg)
         auto add = [&](const float* slabs, int n_slabs, size_t stride, size_t n, float* out, int row_len, int perm) {
-          seg[nseg] = make_seg(slabs, n_slabs, stride, n, inv, out, row_len, perm);
-          ++nseg;
+          pend[n_pend++] = make_seg(slabs, n_slabs, stride, n, inv, out, row_len, perm);
         };
-        add(w.slab, kPhases / big_pps, n1, n1, gr->dw1 + gofs(fl, n1), K1, 3);
-        add(w.part, kPhases / big_pps, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
+        add(w.slab[set], kPhases / big_pps, n1, n1, gr->dw1 + gofs(fl, n1), K1, 3);
+        add(w.part[set], kPhases / big_pps, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
         if (gx) {
-          add(w.slab2, ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C), C, 3);
-          add(w.part2, ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
+          add(w.slab2[set], ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C), C, 3);
+          add(w.part2[set], ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
         }
-        add(w.slab2 + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
+        add(w.slab2[set] + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
         // d out_init = sum over columns of (d b | d log_s), once per flow
-        if (i == 0) add(w.part2 + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k], 0, 0);
-        TR_TRY(launch_slab_reduce_multi(seg, nseg, sW));
+        if (i == 0) add(w.part2[set] + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k], 0, 0);
         TR_ORDER(mark(sW, w_done[i]));
       }
       {
@@ -691,6 +696,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     const SlabSeg sg = make_seg(w.part3, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], 0, 0);
     TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }
+  if (n_pend) TR_TRY(launch_slab_reduce_multi(pend, n_pend, sW));     // the last layer's slabs
   if (flow_lo > 0) {                      // the upsample gradient needs the d pre planes of every flow
     TR_ORDER(order_after(h, sW, s));      // every gradient of the call is final on the caller's stream
     return WG_OK;
@@ -724,7 +730,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.out_scale = inv;
     a.natural_rows = 1;
     a.bias_out = w.part3;                 // (w.part belongs to the weight-gradient stream, still busy with the last layers)
-    TR_TRY(launch_wgrad(a, nullptr, s));
+    TR_TRY(launch_wgrad(a, nullptr, nullptr, 0, s));
     const SlabSeg sg = make_seg(w.part3, kPhases, M8, M8, inv, gr->dbup, M8, 2);
     TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }

@@ -109,8 +109,10 @@ struct PackArgs {
   size_t n_pieces;                    // 16-byte output pieces
 };
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
-// one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle
-hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, hipStream_t s);
+// one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle and a
+// slab reduction `red` (of slabs an earlier launch wrote) whose memory-bound workgroups run beside them
+struct SlabSeg;
+hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, const SlabSeg* red, int n_red, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n  (fixed order: bitwise reproducible), for up to
 // kMaxSlabSegs independent (slabs, out) pairs in ONE launch: a layer's weight-gradient
 // launches leave six small-to-large slab sets behind, and six launches of a few microseconds each cost more in launch
