@@ -388,6 +388,14 @@ def test_custom_grad_scale_and_finite_check(monkeypatch):
   model.grad_scale = 1e30
   WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
   assert not bool(model.grad_finite)
+  # train() hands the flag to the fused optimiser (found_inf): the update is skipped on the device, before the host looks
+  from waveglow_amd.training import load_optimizer
+  opt = load_optimizer(model.parameters(), hp, None)
+  assert any(g.get("fused") for g in opt.param_groups)
+  before = [p.detach().clone() for p in model.parameters()]
+  opt.found_inf = (~model.grad_finite).to(torch.float32).reshape(())
+  opt.step()
+  assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
   monkeypatch.setenv("WG_TRAIN_CHECK_FINITE", "1")
   model.zero_grad()
   with pytest.raises(WgError):

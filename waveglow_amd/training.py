@@ -271,14 +271,22 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
       loss.backward()
       if reducer is not None:
         reducer.reduce()
-      # the reference reads the loss before backward() (train.py:193-195); reading it here -- same value -- leaves ONE host
-      # sync per step, after the backward pass has been queued, instead of a GPU bubble while its ~700 launches are issued
-      reduced_loss = loss.item()
+      # ONE host sync per step, after everything has been queued.  The reference reads the loss before backward()
+      # (train.py:193-195) -- same value here, without a GPU bubble while the backward pass's ~700 launches are issued; and
+      # with the fused optimiser the overflow check gates the update ON THE DEVICE (torch's found_inf hook, as
+      # GradScaler uses it: the step is skipped, nothing is written), so the host reads the flag only afterwards.
       finite = getattr(model, "grad_finite", None)      # set by the library's backward (waveglow_amd/train.py)
-      if finite is not None and not bool(finite):
+      gated = finite is not None and any(g.get("fused") for g in optimizer.param_groups)
+      if gated:
+        optimizer.found_inf = (~finite).to(torch.float32).reshape(())
+      elif finite is not None and not bool(finite):
         from .train import nonfinite_message
         raise Exception(nonfinite_message(float(getattr(model, "grad_scale", 0.0))))
       optimizer.step()
+      reduced_loss = loss.item()
+      if gated and not bool(finite):
+        from .train import nonfinite_message
+        raise Exception(nonfinite_message(float(getattr(model, "grad_scale", 0.0))))
       iteration += 1
       losses.append(reduced_loss)
       end = time.perf_counter()
