@@ -15,8 +15,11 @@ csrc = os.path.join(ROOT, "waveglow_amd", "csrc")
 lib = os.path.join(ROOT, "gpurun_out", "libwaveglow_amd_stamps.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 extra = [f for f in sys.argv[2:] if f.startswith("-D") and f != "-DNONE"]
-subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-                "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "stft.hip", "train.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"], cwd=csrc, check=True)
+if os.environ.get("WG_STAMP_LIB"):          # prebuilt with tools/build_variant.sh <name> "-DWG_STAMPS ..."
+  lib = os.path.abspath(os.environ["WG_STAMP_LIB"])
+else:
+  subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+                  "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "stft.hip", "train.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"], cwd=csrc, check=True)
 os.environ["WAVEGLOW_AMD_LIB"] = lib
 
 import torch  # noqa: E402
@@ -50,10 +53,21 @@ with torch.no_grad():
   m.infer(mel, 0.6)
   torch.cuda.synchronize()
 st = buf.view(n_tiles, 8).cpu().double()
-names = ["prologue (bias, first DMA + A, barrier)", "K loop (GEMM1)", "post-loop loads + gate + acts->LDS + barrier",
-         "GEMM2 (res) incl. acc2 init", "folded end*skip + out RMW", "x_out stores"]
-d = st[:, 1:7] - st[:, 0:6]
-tot = (st[:, 6] - st[:, 0]).mean().item()
+if os.environ.get("WG_STAMP_LAYOUT", "pipe") == "pipe":
+  # pipelined epilogue: stamps 0 top, 1 K loop start, 2 K loop end, 3 / 5 / 6 / 7 end of phases 0..3, 4 end of the last phase
+  order = [0, 1, 2, 3, 5, 6, 7, 4]
+  names = ["prologue (bias, first DMA + A, barrier)", "K loop (GEMM1)", "phase 0 (gate 0, GEMM-2 weight loads)",
+           "phase 1 (gate 1 || GEMM 2 of 0)", "phase 2", "phase 3", "phase 4 (GEMM 2 of 3, end x skip)"]
+  if BN == 64:                                               # two column chunks: phases 0, 1, 2
+    order = [0, 1, 2, 3, 5, 4]
+    names = names[:4] + ["phase 2 (GEMM 2 of 1, end x skip)"]
+else:
+  order = [0, 1, 2, 3, 4, 5, 6]
+  names = ["prologue (bias, first DMA + A, barrier)", "K loop (GEMM1)", "post-loop loads + gate + acts->LDS + barrier",
+           "GEMM2 (res) incl. acc2 init", "folded end*skip + out RMW", "x_out stores"]
+so = st[:, order]
+d = so[:, 1:] - so[:, :-1]
+tot = (so[:, -1] - so[:, 0]).mean().item()
 print(f"C={C} tiles={n_tiles}: mean cycles per workgroup (stamps of the last launch that has a residual: flow 0, layer n_layers-2, dilation 64)")
 for i, n in enumerate(names):
   print(f"  {n:48s} {d[:, i].mean().item():10.0f}  ({100 * d[:, i].mean().item() / tot:5.1f} %)")

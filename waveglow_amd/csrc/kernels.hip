@@ -109,6 +109,34 @@ constexpr bool kPipeEpi = true;       // gate of column chunk c overlapped with 
 // of LDS-DMA (K loop 59.3k vs 57.6k cycles per tile); offsetting the VMEM slots of the two waves of a SIMD
 // (two copies of the loop made hipcc spill).
 
+// Skewed wave groups: the 8 waves of a workgroup run the K loop in lockstep (one barrier per K-step), so a slot's load
+// was issued by all 8 at once -- 8 KiB into a 64 B/clk vector memory path, ~64 cycles of issue stall per load on
+// average, with both waves of a SIMD stalled together (measured: 14 extra loads in one K-step cost 900 cycles).  After
+// every K-loop barrier waves 4-7 (the second wave of each SIMD) sleep kSkew x 64 cycles: their partner has the matrix
+// pipe to itself meanwhile and runs ahead, so from then on the two groups sit in different slots -- half the burst, and
+// a wave stalled in a load's issue has a partner that is issuing MFMAs.  At the step's end the early group waits at
+// the barrier while the late one has the pipe to itself: no MFMA time is lost.
+#ifdef WG_SKEW
+constexpr int kSkew = WG_SKEW;
+#else
+constexpr int kSkew = 0;
+#endif
+#ifdef WG_SKEW_CX1
+constexpr bool kSkewCx1 = true;
+#else
+constexpr bool kSkewCx1 = false;
+#endif
+#ifdef WG_NO_DEEP
+constexpr bool kDeep = false;         // A/B builds: the one-step ring for small workloads too
+#else
+constexpr bool kDeep = true;
+#endif
+#ifdef WG_A2_PRE
+constexpr bool kA2Pre = true;         // GEMM-2 weight fragments fetched inside the LAST K-step (see a2_slot)
+#else
+constexpr bool kA2Pre = false;
+#endif
+
 template <int C> struct WnCfg {
   static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
   static constexpr int BN = (C >= 512) ? 64 : 128;     // columns (group-timesteps) per workgroup
@@ -145,7 +173,13 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 //   2  d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t -+ d)        (NTAPS = 3 taps over the 2C d-pre planes, no cond part)
 //   3  d acts = W_res^T d x_{i+1} + (W_end W_skip)^T d out, then the gate derivative -> d pre   (NTAPS = 1: the d x planes,
 //      "cond" part = the d out plane; the last layer of a flow has no d x: one K-step on the d out plane alone)
-template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true>
+// DEEP = two-step-deep weight prefetch for small workloads (one 64-column tile per CU: every CU streams the layer's whole
+// 1.1 MB of A fragments from L2 for 64 columns, and a K-step is only 1024 MFMA cycles per SIMD, so the ring's prefetch
+// distance of 3/4 step -- ~400 ns -- no longer covers the L2 latency: measured 2086 cycles per K-step, 1196 with the A loads
+// removed).  Two rings Q[parity of the step][quarter]; the quarter consumed in sub-step g of step ks is reloaded with the
+// fragment of step ks + 2.  Every fragment a step needs was issued more than a step earlier, so the step's only wait is
+// the counted one in front of its barrier.  The steps are written out for nK = NKX + 5 (80 mel channels).
+template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
   constexpr bool TR = MODE == 1;         // training forward
   constexpr bool PLAIN = MODE >= 2;      // backward dgrad GEMMs
@@ -163,6 +197,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NAH = MT * 2;            // A fragments per half K-step (packing unit)
   constexpr bool DEFER = (MB == 1);      // defer a step's last sub-step past the barrier (needs spare registers)
   static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 1 && (NTAPS == 1 || NTAPS == 3), "tile geometry");
+  static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && NKX >= 4 && NKX % 2 == 0), "deep prefetch variant");
   static_assert(MODE == 0 || (TPW == 1 && CX == (MODE == 2 ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,10 +365,23 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         for (int i = 0; i < NG; ++i) stage_B_piece(p, jt, 0, par, i);
       }
     }
+    half8 Q[DEEP ? 2 : 1][4][MT];               // DEEP: fragment rings of the even / odd K-steps
+    if constexpr (DEEP) {
+      // issue order A(0, 0..3), A(1, 0..2): the steady state's (see kstep_d)
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+        for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, Q[0][g][mt]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) load_Aq(1, g, mt, Q[DEEP ? 1 : 0][g][mt]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+    }
     // mel rows of the frames this lane gathers for the conditioning K-steps
     if constexpr (MODE == 0) {
 #pragma unroll
@@ -375,6 +423,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v;
     }
 
+    constexpr bool PIPE = !PLAIN && kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
+    // A2PRE needs one load per slot and every slot of the plan filled (the counted waits assume it): C = 256, 128 columns
+    constexpr bool A2PRE = PIPE && kA2Pre && DEFER && MT <= NT && K2 >= 4 * NT - MT && K2 <= 5 * NT - MT;
+    half8 a2r[PIPE ? K2 : 1];                                 // GEMM-2 weight fragments of this wave (pipelined epilogue)
+    const char* const a2_base = (const char*)a.wA2 + (size_t)wave * MB * K2 * 1024;
     // ---- K loop (GEMM 1).  One K-step = 4 k16 sub-steps g = 0..3, each MT*NT MFMAs on fragments q[g][.]
     // (weights) x bf[g&1][.] (activations, read from LDS one sub-step ahead).  Every VMEM / LDS instruction is
     // placed by hand BETWEEN MFMAs (one "slot" after each column tile's MFMAs; sched_barrier pins the order): an
@@ -390,13 +443,20 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     // VMEM issue order per step: DMA xNG, q3 xMT, q0 xMT, q1 xMT, q2 xMT -- every wait is a counted vmcnt.
     // The first and last steps are peeled and "next step is a conditioning step" is a compile-time flag, so the
     // loop bodies are branch-free.
-    wait_vm<0>();
+    wait_vm<DEEP ? 4 * MT : 0>();                // DEEP: A(0, 3) and A(1, .) may still be in flight (steady-state invariant)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     WG_STAMP(1);
     constexpr int LPS = (MT + NT - 1) / NT;      // A-fragment reloads per slot
     constexpr int GPS = (NG + NT - 1) / NT;      // LDS-DMA pieces per slot
     half8 bf[2][NT];
+    // kSkew: the second wave of every SIMD (waves NW/2 ..) falls behind by kSkew x 64 cycles after each K-loop barrier
+    auto skew_wait = [&]() {
+      if constexpr (kSkew > 0 && NW == 8 && (CX != 1 || kSkewCx1)) {
+        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lsk%=\n\ts_sleep %1\n.Lsk%=:" :: "s"(wave), "i"(kSkew) : "memory", "scc");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     auto mfma_col = [&](int g, int nt) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -427,6 +487,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           }
         }
       };
+      // A2PRE: the LAST K-step issues no DMA and no A reloads for a next step, so the vector memory path idles for a
+      // whole step while the matrix pipe is busy -- the wave's K2 GEMM-2 weight fragments (1 KiB each, K2 x 8 waves =
+      // 128 KiB per CU, a quarter of a K-step's whole A stream) go out there, one per slot, instead of inside phase 0 of
+      // the epilogue, where their issue time came on top of the VALU-bound gate.  Hand-counted like the q loads:
+      //   D slots: a2r[0..NT) ; g=0: q3 x MT, then a2r in the slots left ; g=1, g=2: one per slot ; rest: final D slots.
+      constexpr bool a2pre = A2PRE && !more;
+      constexpr int A2_G0 = a2pre ? NT - MT : 0;               // a2r loads in the g = 0 slots (behind the MT q[3] reloads)
+      auto a2_load = [&](int i) { gload16<0>(a2r[i], a2_base + (size_t)i * 1024, a_voff); };
+      skew_wait();
       if constexpr (DEFER) {
         // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
 #pragma unroll
@@ -434,13 +503,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           if constexpr (!first) mfma_col(3, nt);
           __builtin_amdgcn_sched_barrier(0);
           dma_slot(nt);
+          if constexpr (a2pre) a2_load(nt);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
       for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
-        if (g == 1) wait_vm<more ? 2 * MT + NG : 2 * MT>();      // q[1] landed
-        if (g == 2) wait_vm<more ? NG + 2 * MT : MT>();          // q[2] landed
+        // outstanding behind q[1]: q[2] x MT, (DMA | a2r x NT), q[3] x MT, a2r x A2_G0
+        if (g == 1) wait_vm<more ? 2 * MT + NG : (a2pre ? 2 * MT + NT + A2_G0 : 2 * MT)>();      // q[1] landed
+        if (g == 2) wait_vm<more ? NG + 2 * MT : (a2pre ? MT + 2 * NT + A2_G0 : MT)>();          // q[2] landed
         if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -452,6 +523,10 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
             for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
               load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
+          }
+          if constexpr (a2pre) {
+            if (g == 0 && nt >= MT) a2_load(NT + nt - MT);
+            if (g >= 1) a2_load(NT + A2_G0 + (g - 1) * NT + nt);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -468,7 +543,89 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    {
+    // ---- DEEP K-step.  VMEM issue order per step: DMA(ks+1) x NG, A(ks+1, 3) x MT, A(ks+2, 0), A(ks+2, 1), A(ks+2, 2);
+    // the wait in front of the barrier -- at most A(ks+1, 3) and A(ks+2, .) outstanding -- covers the B tile and every
+    // fragment step ks+1 uses.  P = parity of ks; sub-step 3 of step ks-1 (ring P^1) is the deferred one.
+    auto kstep_d = [&](auto par_tag, auto more_tag, auto more2_tag, auto ncond_tag, auto first_tag, int ks) {
+      constexpr int P = DEEP ? decltype(par_tag)::value : 0, PO = DEEP ? 1 - P : 0;
+      constexpr bool more = decltype(more_tag)::value, more2 = decltype(more2_tag)::value;
+      constexpr bool ncond = decltype(ncond_tag)::value, first = decltype(first_tag)::value;
+      const char* buf = sB + ((ks + par) & 1) * BT_BYTES;
+      const char* src_next = nullptr;
+      if constexpr (more && !ncond) src_next = xstep_src(p, jt, ks + 1);
+      const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (!first) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Q[PO][3][mt], bf[1][nt], acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) {
+          if (nt < NG) {
+            const unsigned lds = __builtin_amdgcn_readfirstlane(lds_next + nt * NTHREADS * 16);
+            if constexpr (ncond) glds16(a.melT, cond_voff(ks + 1 - NKX, nt), lds);
+            else glds16(src_next, pvoff[nt], lds);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Q[P][g][mt], bf[g & 1][nt], acc[mt][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bf[(g + 1) & 1][nt] = read_B(buf, nt, g + 1);
+          if (nt < MT) {
+            if (g == 0 && more) load_Aq(ks + 1, 3, nt, Q[PO][3][nt]);
+            if (g >= 1 && more2) load_Aq(ks + 2, g - 1, nt, Q[P][g - 1][nt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (more2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 2, 2, mt, Q[P][2][mt]);
+      }
+      if constexpr (more) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(more2 ? 4 * MT : MT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (DEEP) {
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      using P0 = std::integral_constant<int, 0>;
+      using P1 = std::integral_constant<int, 1>;
+      //        parity more  more2 ncond first
+      kstep_d(P0{}, T_{}, T_{}, F_{}, T_{}, 0);
+#pragma clang loop unroll(disable)
+      for (int ks = 1; ks < NKX - 1; ks += 2) {                       // NKX even: pairs (odd, even)
+        kstep_d(P1{}, T_{}, T_{}, F_{}, F_{}, ks);
+        kstep_d(P0{}, T_{}, T_{}, F_{}, F_{}, ks + 1);
+      }
+      kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, NKX - 1);                 // last tap step: the next B tile is a conditioning tile
+      kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, NKX);                     // five conditioning steps (the host checks n_cond_steps)
+      kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, NKX + 1);
+      kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, NKX + 2);
+      kstep_d(P1{}, T_{}, F_{}, T_{}, F_{}, NKX + 3);
+      kstep_d(P0{}, F_{}, F_{}, F_{}, F_{}, NKX + 4);
+      wait_vm<0>();                                                   // A(nK-1, 3)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Q[0][3][mt], bf[1][nt], acc[mt][nt], 0, 0, 0);
+    }
+    if constexpr (!DEEP) {
       using T_ = std::true_type;
       using F_ = std::false_type;
       if constexpr (NKX == 1) {
@@ -487,10 +644,23 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         kstep(F_{}, F_{}, F_{}, nK - 1);                            // last conditioning step
       }
     }
-    if constexpr (DEFER) {
-      wait_vm<0>();                          // q[3] of the last step
+    if constexpr (DEFER && !DEEP) {
+      if constexpr (A2PRE) {
+        constexpr int A2_G0 = NT - MT, A2_DONE = 3 * NT + A2_G0;     // a2r loads issued inside the last step
+        wait_vm<A2_G0 + 2 * NT>();             // q[3] of the last step (behind it: the a2r loads of g = 0, 1, 2)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) mfma_col(3, nt);
+        for (int nt = 0; nt < NT; ++nt) {
+          mfma_col(3, nt);
+          __builtin_amdgcn_sched_barrier(0);
+          if (A2_DONE + nt < K2) gload16<0>(a2r[A2_DONE + nt], a2_base + (size_t)(A2_DONE + nt) * 1024, a_voff);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_vm<0>();                          // every a2r fragment has landed before compiler-scheduled code sees them
+      } else {
+        wait_vm<0>();                          // q[3] of the last step
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mfma_col(3, nt);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     par = (par + nK) & 1;
@@ -612,7 +782,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         }
       }
     };
-    constexpr bool PIPE = kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
     auto read_acts32 = [&](int nt, int k16) -> half8 {       // B fragment for the 32x32x16 MFMA
       return *(const half8*)(acts_rd + nt * 32 * ACT_ROW + k16 * 32);
     };
@@ -634,7 +803,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       // chunks already gated are dead by then, and a chunk's acc2 is only 16 registers.
       constexpr int SL = 16;                                  // slots per phase = gate elements per lane and chunk
       const int blk = wave;                                   // MB == 1
-      half8 a2r[K2];                                          // loaded in the slots of phase 0 (first use: phase 1)
+      // a2r: loaded in the slots of phase 0 (first use: phase 1), or already inside the last K-step (A2PRE)
       const float* const sBias2 = sBias + 2 * C;              // b_res, fp32 [C], staged next to the GEMM-1 bias
       // Residual add (model.py:131-132) on the matrix pipe: x_out = b_res + P x + W_res acts, where P selects this
       // wave's 32 channels of x -- two more k16 steps whose A fragments are a constant 0/1 matrix (row r = natural
@@ -743,7 +912,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if (has_k(i + 2)) bq[k_of(i + 2)] = read_acts32(ntm, k_of(i + 2));   // fragment read two slots ahead
             if (has_k(i)) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2r[k_of(i)], bq[k_of(i)], d2, 0, 0, 0);
           }
-          if (c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
+          if (!A2PRE && c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
           if (do_gate) {
             if (i + 2 < SL) stageA(i + 2);
             if (i + 1 < SL) stageB(i + 1);
@@ -781,6 +950,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           if (c == 0) WG_STAMP(3);
+          if (c == 1) WG_STAMP(5);
+          if (c == 2) WG_STAMP(6);
+          if (c == 3) WG_STAMP(7);
         }
       };
       phase(std::integral_constant<int, 0>{});
@@ -903,7 +1075,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       es_compute();
     }
 
-    WG_STAMP(5);
+    if constexpr (!PIPE) WG_STAMP(5);
     // ---- x_out = fp16(x + res) for valid columns (all other rows stay zero: they are the padding of other tiles)
     if constexpr (HAS_RES && !PIPE) {
 #pragma unroll
@@ -927,19 +1099,19 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         }
       }
     }
-    WG_STAMP(6);
+    if constexpr (!PIPE) WG_STAMP(6);
     }   // !PLAIN
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's prologue (128 accumulator inits) out of this epilogue
   }
 }
 
-template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true>
+template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
@@ -947,12 +1119,16 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   // TPW tiles per workgroup: per XCD label ceil(tiles_on_label / TPW) blocks
   const int per_label = ((a.n_tiles + 7) / 8 + TPW - 1) / TPW;
   const int grid = 8 * per_label;
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND>), dim3(grid), dim3(NW * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
 }
 template <int C, int BN, bool HAS_RES, int TPW>
 static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
   if (a.x_chunks_per_tap == 1) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
+  // small workloads (one tile per workgroup, 64 columns) at 256 channels / 80 mel channels: two-step-deep weight prefetch
+  if constexpr (kDeep && C == 256 && BN == 64 && TPW == 1) {
+    if (a.n_cond_steps == 5) return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64, 0, 3, true, true>(a, s);
+  }
   return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64>(a, s);
 }
 template <int C, int BN, bool HAS_RES>
@@ -1171,8 +1347,9 @@ hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* ou
 // =============================================================================================
 // Flow step (both directions) + next WN start.  64 rows per workgroup, 256 threads.
 // =============================================================================================
-constexpr int FL_ROWS = 256;   // rows per workgroup = threads per workgroup
-
+// FL_ROWS rows per workgroup = threads per workgroup: 256, or 64 for small workloads (a single utterance of 500 frames
+// is 16 000 rows: 63 workgroups of 256 left three quarters of the chip idle, 21 us per launch x 13 launches).
+template <int FL_ROWS>
 __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
   __shared__ float4 s_a0[FL_ROWS];
   const int L = a.g.L;
@@ -1362,8 +1539,11 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
 
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s) {
   const size_t nrows = (size_t)a.g.B * a.g.L;
-  const unsigned grid = (unsigned)((nrows + FL_ROWS - 1) / FL_ROWS);
-  hipLaunchKernelGGL(flow_kernel, dim3(grid), dim3(FL_ROWS), 0, s, a);
+  if (nrows < 256 * 256) {
+    hipLaunchKernelGGL(flow_kernel<64>, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(flow_kernel<256>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 
