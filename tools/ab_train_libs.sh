@@ -1,0 +1,10 @@
+#!/bin/bash
+# Interleaved training-step bench of the in-tree library (A) and prebuilt variant libraries on ONE box.
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+ROUNDS=${ROUNDS:-2}
+for round in $(seq 1 $ROUNDS); do
+  for v in "" "$@"; do
+    if [ -z "$v" ]; then unset WAVEGLOW_AMD_LIB; name="A (in-tree)"; else export WAVEGLOW_AMD_LIB=$ROOT/$v; name=$(basename $v .so); fi
+    timeout -k 10 300 python $ROOT/tools/bench_train.py --adam --steps 8 --warmup 3 2>/dev/null | tail -1 | cut -c1-200 | sed "s/^/$name round $round: /"
+  done
+done

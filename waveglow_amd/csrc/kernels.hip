@@ -126,6 +126,25 @@ constexpr bool kSkewCx1 = true;
 #else
 constexpr bool kSkewCx1 = false;
 #endif
+// Alternating issue priority (experiment): the SIMD arbiter favours the older of its two waves, so one wave runs a whole K-step
+// ahead of its partner and then idles at the barrier while the partner finishes alone, its load-issue stalls uncovered
+// (without the barrier wave 0 finishes the K loop in 28 k cycles, its partner in 44 k).  kPrio != 0: the two waves of a
+// SIMD take turns at s_setprio 1, one sub-step (8 MFMAs) each.
+#ifdef WG_PRIO
+constexpr int kPrio = WG_PRIO;
+#else
+constexpr int kPrio = 0;
+#endif
+#ifdef WG_PRIO_OLD
+constexpr bool kPrioOld = true;       // priority switches in front of a sub-step (own scheduling barrier) instead of inside the slot before it
+#else
+constexpr bool kPrioOld = false;
+#endif
+#ifdef WG_PRIO_WIDE
+constexpr bool kPrioWide = true;      // also the first-layer variant and the training forward
+#else
+constexpr bool kPrioWide = false;
+#endif
 #ifdef WG_NO_DEEP
 constexpr bool kDeep = false;         // A/B builds: the one-step ring for small workloads too
 #else
@@ -457,6 +476,36 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    constexpr bool PRIO = kPrio != 0 && NW == 8 && BN == 128 && ((MODE == 0 && CX == C / 64) || (kPrioWide && MODE == 1));
+    // hi_grp = 1: waves 4-7 raise their priority (waves 0-3 drop to 0); 0: the other way round
+    auto prio_set = [&](int hi_grp) {
+      if constexpr (kPrio >= 8) {
+        // group = bit 0 of the wave's slot on its SIMD (HW_REG_HW_ID.WAVE_ID): no live register needed
+        unsigned t;
+        if (hi_grp == 1)
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 1\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 0\n.Lpb%=:" : "=&s"(t) :: "memory", "scc");
+        else
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 0\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 1\n.Lpb%=:" : "=&s"(t) :: "memory", "scc");
+      } else if (hi_grp == 1)
+        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 1\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 0\n.Lpb%=:" :: "s"(wave) : "memory", "scc");
+      else
+        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 0\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 1\n.Lpb%=:" :: "s"(wave) : "memory", "scc");
+    };
+    // sub = 0: start of the step (before the deferred sub-step), 1..3: before sub-step g = sub - 1
+    auto prio_turn = [&](int sub) {
+      if constexpr (PRIO) {
+        if (kPrio == 1) { if (sub == 0) prio_set(1); if (sub == 2) prio_set(0); }      // halves: 4-7 first
+        if (kPrio == 2) { if (sub == 0) prio_set(0); if (sub == 2) prio_set(1); }      // halves: 0-3 first
+        if (kPrio == 5) { if (sub == 0) prio_set(1); if (sub == 3) prio_set(0); }      // 3/4 : 1/4
+        if (kPrio == 6) { if (sub == 0) prio_set(1); if (sub == 1) prio_set(0); }      // 1/4 : 3/4
+        if (kPrio == 7) { if (sub == 0 || sub == 2) prio_set(1); if (sub == 1 || sub == 3) prio_set(0); }   // quarters
+        if (kPrio == 8) { if (sub == 0) prio_set(1); if (sub == 2) prio_set(0); }      // halves, groups by hardware slot
+        if (kPrio == 9) { if (sub == 0) prio_set(0); if (sub == 2) prio_set(1); }
+        if (kPrio == 10) { if (sub == 0 || sub == 2) prio_set(1); if (sub == 1 || sub == 3) prio_set(0); }  // quarters
+        if (kPrio == 11) { if (sub == 0 || sub == 2) prio_set(0); if (sub == 1 || sub == 3) prio_set(1); }
+      }
+    };
+    if constexpr (PRIO && (kPrio == 3 || kPrio == 4)) prio_set(kPrio == 3 ? 1 : 0);    // static: one group always ahead
     auto mfma_col = [&](int g, int nt) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -496,6 +545,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       constexpr int A2_G0 = a2pre ? NT - MT : 0;               // a2r loads in the g = 0 slots (behind the MT q[3] reloads)
       auto a2_load = [&](int i) { gload16<0>(a2r[i], a2_base + (size_t)i * 1024, a_voff); };
       skew_wait();
+      prio_turn(0);
+      if constexpr (PRIO) __builtin_amdgcn_sched_barrier(0);
       if constexpr (DEFER) {
         // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
 #pragma unroll
@@ -503,6 +554,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           if constexpr (!first) mfma_col(3, nt);
           __builtin_amdgcn_sched_barrier(0);
           dma_slot(nt);
+          if (!kPrioOld && nt == NT - 1) prio_turn(1);
           if constexpr (a2pre) a2_load(nt);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -513,6 +565,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         if (g == 1) wait_vm<more ? 2 * MT + NG : (a2pre ? 2 * MT + NT + A2_G0 : 2 * MT)>();      // q[1] landed
         if (g == 2) wait_vm<more ? NG + 2 * MT : (a2pre ? MT + 2 * NT + A2_G0 : MT)>();          // q[2] landed
         if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
+        if constexpr (kPrioOld && PRIO) {
+          if (g >= 1) { prio_turn(g + 1); __builtin_amdgcn_sched_barrier(0); }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           mfma_col(g, nt);
@@ -524,6 +579,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
               load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
           }
+          if (!kPrioOld && nt == NT - 1 && g < 2) prio_turn(g + 2);
           if constexpr (a2pre) {
             if (g == 0 && nt >= MT) a2_load(NT + nt - MT);
             if (g >= 1) a2_load(NT + A2_G0 + (g - 1) * NT + nt);
@@ -662,6 +718,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         for (int nt = 0; nt < NT; ++nt) mfma_col(3, nt);
       }
     }
+    if constexpr (PRIO) asm volatile("s_setprio 0" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     par = (par + nK) & 1;
     // Next tile's first B tile goes out now, into the LDS buffer the last step did not use (slow waves may
