@@ -5,6 +5,12 @@ ROUNDS=${ROUNDS:-2}
 for round in $(seq 1 $ROUNDS); do
   for v in "" "$@"; do
     if [ -z "$v" ]; then unset WAVEGLOW_AMD_LIB; name="A (in-tree)"; else export WAVEGLOW_AMD_LIB=$ROOT/$v; name=$(basename $v .so); fi
-    timeout -k 10 300 python $ROOT/tools/bench_train.py --adam --steps 8 --warmup 3 2>/dev/null | tail -1 | cut -c1-200 | sed "s/^/$name round $round: /"
+    timeout -k 10 300 python $ROOT/tools/bench_train.py --adam --steps 8 --warmup 3 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+  if l.startswith('{'):
+    d = json.loads(l)
+    print('$name round $round:', ' '.join('%s %.2f' % (k, v) for k, v in d.items() if k.startswith('ms_')))
+"
   done
 done

@@ -109,51 +109,26 @@ constexpr bool kPipeEpi = true;       // gate of column chunk c overlapped with 
 // of LDS-DMA (K loop 59.3k vs 57.6k cycles per tile); offsetting the VMEM slots of the two waves of a SIMD
 // (two copies of the loop made hipcc spill).
 
-// Skewed wave groups: the 8 waves of a workgroup run the K loop in lockstep (one barrier per K-step), so a slot's load
-// was issued by all 8 at once -- 8 KiB into a 64 B/clk vector memory path, ~64 cycles of issue stall per load on
-// average, with both waves of a SIMD stalled together (measured: 14 extra loads in one K-step cost 900 cycles).  After
-// every K-loop barrier waves 4-7 (the second wave of each SIMD) sleep kSkew x 64 cycles: their partner has the matrix
-// pipe to itself meanwhile and runs ahead, so from then on the two groups sit in different slots -- half the burst, and
-// a wave stalled in a load's issue has a partner that is issuing MFMAs.  At the step's end the early group waits at
-// the barrier while the late one has the pipe to itself: no MFMA time is lost.
-#ifdef WG_SKEW
-constexpr int kSkew = WG_SKEW;
+// Alternating issue priority in the K loop.  The SIMD arbiter favours the older of its two waves: one wave runs a whole
+// K-step ahead of its partner, then idles at the barrier while the partner finishes alone with its load-issue stalls
+// uncovered (with the barrier removed, wave 0 is through the K loop in 28 k cycles and its partner in 44 k).  With kPrio the
+// two waves of a SIMD take turns at s_setprio 1: waves 4-7 during the deferred sub-step and sub-step 0, waves 0-3 during
+// sub-steps 1 and 2.  Same-box A/B: +0.4 ... +1.2 % on the inference kernel (box dependent), -0.4 ms on the training
+// forward.  Measured and dropped: the other phase (-1.1 %), either group always ahead (-0.1 / -0.3 %), a 1/4 : 3/4 split
+// (-0.4 %); switches in front of sub-step 2 (quarters, 3/4 : 1/4) and any switch in the first-layer variant make hipcc spill.
+#ifdef WG_NO_PRIO
+constexpr bool kPrio = false;         // A/B builds
 #else
-constexpr int kSkew = 0;
+constexpr bool kPrio = true;
 #endif
-#ifdef WG_SKEW_CX1
-constexpr bool kSkewCx1 = true;
-#else
-constexpr bool kSkewCx1 = false;
-#endif
-// Alternating issue priority (experiment): the SIMD arbiter favours the older of its two waves, so one wave runs a whole K-step
-// ahead of its partner and then idles at the barrier while the partner finishes alone, its load-issue stalls uncovered
-// (without the barrier wave 0 finishes the K loop in 28 k cycles, its partner in 44 k).  kPrio != 0: the two waves of a
-// SIMD take turns at s_setprio 1, one sub-step (8 MFMAs) each.
-#ifdef WG_PRIO
-constexpr int kPrio = WG_PRIO;
-#else
-constexpr int kPrio = 0;
-#endif
-#ifdef WG_PRIO_OLD
-constexpr bool kPrioOld = true;       // priority switches in front of a sub-step (own scheduling barrier) instead of inside the slot before it
-#else
-constexpr bool kPrioOld = false;
-#endif
-#ifdef WG_PRIO_WIDE
-constexpr bool kPrioWide = true;      // also the first-layer variant and the training forward
-#else
-constexpr bool kPrioWide = false;
-#endif
+// (Also measured and dropped, round 2: waves 4-7 sleeping 64-192 cycles after every K-loop barrier to de-phase the two
+// groups' loads: -0.5 %; the GEMM-2 weight fragments fetched inside the last K-step instead of phase 0 of the epilogue:
+// phase 0 -1.2 k cycles, K loop +0.9 k, +-0.1 % end to end; both waves' loads moved to different slots by branches inside
+// the load statements: the "+v" ties make hipcc copy fragment registers, and the K loop spills.)
 #ifdef WG_NO_DEEP
 constexpr bool kDeep = false;         // A/B builds: the one-step ring for small workloads too
 #else
 constexpr bool kDeep = true;
-#endif
-#ifdef WG_A2_PRE
-constexpr bool kA2Pre = true;         // GEMM-2 weight fragments fetched inside the LAST K-step (see a2_slot)
-#else
-constexpr bool kA2Pre = false;
 #endif
 
 template <int C> struct WnCfg {
@@ -443,10 +418,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     }
 
     constexpr bool PIPE = !PLAIN && kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
-    // A2PRE needs one load per slot and every slot of the plan filled (the counted waits assume it): C = 256, 128 columns
-    constexpr bool A2PRE = PIPE && kA2Pre && DEFER && MT <= NT && K2 >= 4 * NT - MT && K2 <= 5 * NT - MT;
     half8 a2r[PIPE ? K2 : 1];                                 // GEMM-2 weight fragments of this wave (pipelined epilogue)
-    const char* const a2_base = (const char*)a.wA2 + (size_t)wave * MB * K2 * 1024;
     // ---- K loop (GEMM 1).  One K-step = 4 k16 sub-steps g = 0..3, each MT*NT MFMAs on fragments q[g][.]
     // (weights) x bf[g&1][.] (activations, read from LDS one sub-step ahead).  Every VMEM / LDS instruction is
     // placed by hand BETWEEN MFMAs (one "slot" after each column tile's MFMAs; sched_barrier pins the order): an
@@ -469,43 +441,16 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     constexpr int LPS = (MT + NT - 1) / NT;      // A-fragment reloads per slot
     constexpr int GPS = (NG + NT - 1) / NT;      // LDS-DMA pieces per slot
     half8 bf[2][NT];
-    // kSkew: the second wave of every SIMD (waves NW/2 ..) falls behind by kSkew x 64 cycles after each K-loop barrier
-    auto skew_wait = [&]() {
-      if constexpr (kSkew > 0 && NW == 8 && (CX != 1 || kSkewCx1)) {
-        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lsk%=\n\ts_sleep %1\n.Lsk%=:" :: "s"(wave), "i"(kSkew) : "memory", "scc");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    constexpr bool PRIO = kPrio != 0 && NW == 8 && BN == 128 && ((MODE == 0 && CX == C / 64) || (kPrioWide && MODE == 1));
-    // hi_grp = 1: waves 4-7 raise their priority (waves 0-3 drop to 0); 0: the other way round
+    // kPrio (see the knob): waves 4-7 hold the raised priority through the deferred sub-step and sub-step 0, waves 0-3
+    // through sub-steps 1 and 2; the switch sits inside the last slot of the sub-step before.  The training forward has it
+    // too; the first-layer variants (CX = 1) spill with it and go without.
+    constexpr bool PRIO = kPrio && NW == 8 && BN == 128 && ((MODE == 0 && CX == C / 64) || MODE == 1);
     auto prio_set = [&](int hi_grp) {
-      if constexpr (kPrio >= 8) {
-        // group = bit 0 of the wave's slot on its SIMD (HW_REG_HW_ID.WAVE_ID): no live register needed
-        unsigned t;
-        if (hi_grp == 1)
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 1\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 0\n.Lpb%=:" : "=&s"(t) :: "memory", "scc");
-        else
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 0\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 1\n.Lpb%=:" : "=&s"(t) :: "memory", "scc");
-      } else if (hi_grp == 1)
+      if (hi_grp == 1)
         asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 1\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 0\n.Lpb%=:" :: "s"(wave) : "memory", "scc");
       else
         asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 0\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 1\n.Lpb%=:" :: "s"(wave) : "memory", "scc");
     };
-    // sub = 0: start of the step (before the deferred sub-step), 1..3: before sub-step g = sub - 1
-    auto prio_turn = [&](int sub) {
-      if constexpr (PRIO) {
-        if (kPrio == 1) { if (sub == 0) prio_set(1); if (sub == 2) prio_set(0); }      // halves: 4-7 first
-        if (kPrio == 2) { if (sub == 0) prio_set(0); if (sub == 2) prio_set(1); }      // halves: 0-3 first
-        if (kPrio == 5) { if (sub == 0) prio_set(1); if (sub == 3) prio_set(0); }      // 3/4 : 1/4
-        if (kPrio == 6) { if (sub == 0) prio_set(1); if (sub == 1) prio_set(0); }      // 1/4 : 3/4
-        if (kPrio == 7) { if (sub == 0 || sub == 2) prio_set(1); if (sub == 1 || sub == 3) prio_set(0); }   // quarters
-        if (kPrio == 8) { if (sub == 0) prio_set(1); if (sub == 2) prio_set(0); }      // halves, groups by hardware slot
-        if (kPrio == 9) { if (sub == 0) prio_set(0); if (sub == 2) prio_set(1); }
-        if (kPrio == 10) { if (sub == 0 || sub == 2) prio_set(1); if (sub == 1 || sub == 3) prio_set(0); }  // quarters
-        if (kPrio == 11) { if (sub == 0 || sub == 2) prio_set(0); if (sub == 1 || sub == 3) prio_set(1); }
-      }
-    };
-    if constexpr (PRIO && (kPrio == 3 || kPrio == 4)) prio_set(kPrio == 3 ? 1 : 0);    // static: one group always ahead
     auto mfma_col = [&](int g, int nt) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -536,17 +481,10 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           }
         }
       };
-      // A2PRE: the LAST K-step issues no DMA and no A reloads for a next step, so the vector memory path idles for a
-      // whole step while the matrix pipe is busy -- the wave's K2 GEMM-2 weight fragments (1 KiB each, K2 x 8 waves =
-      // 128 KiB per CU, a quarter of a K-step's whole A stream) go out there, one per slot, instead of inside phase 0 of
-      // the epilogue, where their issue time came on top of the VALU-bound gate.  Hand-counted like the q loads:
-      //   D slots: a2r[0..NT) ; g=0: q3 x MT, then a2r in the slots left ; g=1, g=2: one per slot ; rest: final D slots.
-      constexpr bool a2pre = A2PRE && !more;
-      constexpr int A2_G0 = a2pre ? NT - MT : 0;               // a2r loads in the g = 0 slots (behind the MT q[3] reloads)
-      auto a2_load = [&](int i) { gload16<0>(a2r[i], a2_base + (size_t)i * 1024, a_voff); };
-      skew_wait();
-      prio_turn(0);
-      if constexpr (PRIO) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PRIO) {
+        prio_set(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (DEFER) {
         // ---- D: deferred sub-step 3 of step ks-1 + DMA of tile ks+1
 #pragma unroll
@@ -554,20 +492,14 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           if constexpr (!first) mfma_col(3, nt);
           __builtin_amdgcn_sched_barrier(0);
           dma_slot(nt);
-          if (!kPrioOld && nt == NT - 1) prio_turn(1);
-          if constexpr (a2pre) a2_load(nt);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
       for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
-        // outstanding behind q[1]: q[2] x MT, (DMA | a2r x NT), q[3] x MT, a2r x A2_G0
-        if (g == 1) wait_vm<more ? 2 * MT + NG : (a2pre ? 2 * MT + NT + A2_G0 : 2 * MT)>();      // q[1] landed
-        if (g == 2) wait_vm<more ? NG + 2 * MT : (a2pre ? MT + 2 * NT + A2_G0 : MT)>();          // q[2] landed
+        if (g == 1) wait_vm<more ? 2 * MT + NG : 2 * MT>();      // q[1] landed
+        if (g == 2) wait_vm<more ? NG + 2 * MT : MT>();          // q[2] landed
         if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
-        if constexpr (kPrioOld && PRIO) {
-          if (g >= 1) { prio_turn(g + 1); __builtin_amdgcn_sched_barrier(0); }
-        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           mfma_col(g, nt);
@@ -579,10 +511,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
               load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
           }
-          if (!kPrioOld && nt == NT - 1 && g < 2) prio_turn(g + 2);
-          if constexpr (a2pre) {
-            if (g == 0 && nt >= MT) a2_load(NT + nt - MT);
-            if (g >= 1) a2_load(NT + A2_G0 + (g - 1) * NT + nt);
+          if constexpr (PRIO) {
+            if (g == 0 && nt == NT - 1) prio_set(0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -701,22 +631,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     }
     if constexpr (DEFER && !DEEP) {
-      if constexpr (A2PRE) {
-        constexpr int A2_G0 = NT - MT, A2_DONE = 3 * NT + A2_G0;     // a2r loads issued inside the last step
-        wait_vm<A2_G0 + 2 * NT>();             // q[3] of the last step (behind it: the a2r loads of g = 0, 1, 2)
+      wait_vm<0>();                            // q[3] of the last step
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          mfma_col(3, nt);
-          __builtin_amdgcn_sched_barrier(0);
-          if (A2_DONE + nt < K2) gload16<0>(a2r[A2_DONE + nt], a2_base + (size_t)(A2_DONE + nt) * 1024, a_voff);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        wait_vm<0>();                          // every a2r fragment has landed before compiler-scheduled code sees them
-      } else {
-        wait_vm<0>();                          // q[3] of the last step
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mfma_col(3, nt);
-      }
+      for (int nt = 0; nt < NT; ++nt) mfma_col(3, nt);
     }
     if constexpr (PRIO) asm volatile("s_setprio 0" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -860,7 +777,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       // chunks already gated are dead by then, and a chunk's acc2 is only 16 registers.
       constexpr int SL = 16;                                  // slots per phase = gate elements per lane and chunk
       const int blk = wave;                                   // MB == 1
-      // a2r: loaded in the slots of phase 0 (first use: phase 1), or already inside the last K-step (A2PRE)
+      // a2r: loaded in the slots of phase 0 (first use: phase 1)
       const float* const sBias2 = sBias + 2 * C;              // b_res, fp32 [C], staged next to the GEMM-1 bias
       // Residual add (model.py:131-132) on the matrix pipe: x_out = b_res + P x + W_res acts, where P selects this
       // wave's 32 channels of x -- two more k16 steps whose A fragments are a constant 0/1 matrix (row r = natural
@@ -969,7 +886,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if (has_k(i + 2)) bq[k_of(i + 2)] = read_acts32(ntm, k_of(i + 2));   // fragment read two slots ahead
             if (has_k(i)) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2r[k_of(i)], bq[k_of(i)], d2, 0, 0, 0);
           }
-          if (!A2PRE && c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
+          if (c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
           if (do_gate) {
             if (i + 2 < SL) stageA(i + 2);
             if (i + 1 < SL) stageB(i + 1);
