@@ -88,6 +88,18 @@ def _dense_stack(mods) -> torch.Tensor:
   return torch.stack([m.weight for m in mods])
 
 
+def _shape_runs(sizes):
+  """[(size, [flow indices])] for maximal runs of consecutive flows with equal size (flow order is kept by concatenating
+  the runs)."""
+  runs = []
+  for k, r in enumerate(sizes):
+    if runs and runs[-1][0] == r:
+      runs[-1][1].append(k)
+    else:
+      runs.append((r, [k]))
+  return runs
+
+
 def pack_weights(model) -> Tuple[torch.Tensor, ...]:
   """Differentiable packing of the module's parameters into the stacked matrices of wg_train_weights, in NATURAL
   channel order (to_pos_order applies the kernels' permutation).
@@ -118,26 +130,19 @@ def pack_weights(model) -> Tuple[torch.Tensor, ...]:
     w2 = torch.zeros_like(last_w)
     b2 = torch.zeros_like(last_b)
     w_skips, b_skip_sum = last_w[:, None], last_b
+  # Per-flow small tensors (end, start, 1x1): flows of one shape (h_k changes at the early outputs) are stacked and padded as
+  # ONE tensor per shape group -- a per-flow formulation costs ~25 tiny kernels per flow and step each way.
+  runs = _shape_runs([WN[k].end.weight.shape[0] for k in range(nf)])
   # WN.end (not weight-normed, 2h_k rows) zero-padded to 8 rows: end(sum_i skip_i) for every flow in one batched GEMM
-  w_end8 = torch.stack([pad(WN[k].end.weight.squeeze(2), (0, 0, 0, 8 - WN[k].end.weight.shape[0])) for k in range(nf)])
-  b_end8 = torch.stack([pad(WN[k].end.bias, (0, 8 - WN[k].end.bias.shape[0])) for k in range(nf)])
+  w_end8 = torch.cat([pad(torch.stack([WN[k].end.weight.squeeze(2) for k in ks]), (0, 0, 0, 8 - r)) for r, ks in runs])
+  b_end8 = torch.cat([pad(torch.stack([WN[k].end.bias for k in ks]), (0, 8 - r)) for r, ks in runs])
   wes = torch.matmul(w_end8[:, None], w_skips).reshape(nf * nl, 8, Cc)           # [nf, nl, 8, C]
   out_init = torch.bmm(w_end8, b_skip_sum[:, :, None]).squeeze(2) + b_end8       # [nf, 8]
-  # start conv [C, h_k] (h_k differs per flow: weight norm per shape group), zero-padded to 4 columns, + bias row
-  by_shape = {}
-  for k in range(nf):
-    by_shape.setdefault(tuple(WN[k].start.weight.shape) if not torch.nn.utils.parametrize.is_parametrized(WN[k].start, "weight")
-                        else tuple(WN[k].start.parametrizations.weight.original1.shape), []).append(k)
-  ws_of = {}
-  for ks in by_shape.values():
-    st = _dense_stack([WN[k].start for k in ks]).squeeze(3)                      # [n, C, h]
-    for j, k in enumerate(ks):
-      ws_of[k] = st[j]
-  start5 = torch.stack([torch.cat([pad(ws_of[k], (0, 4 - ws_of[k].shape[1])).t(), WN[k].start.bias[None, :]], 0)
-                        for k in range(nf)])                                     # [nf, 5, C]
-  w1x1 = torch.stack([pad(model.convinv[k].conv.weight.squeeze(2),
-                          (0, 8 - model.convinv[k].conv.weight.shape[1], 0, 8 - model.convinv[k].conv.weight.shape[0]))
-                      for k in range(nf)])
+  # start conv [C, h_k] (weight norm per shape group), zero-padded to 4 columns, + bias row -> [nf, 5, C]
+  start5 = torch.cat([torch.cat([pad(_dense_stack([WN[k].start for k in ks]).squeeze(3), (0, 4 - r // 2)).transpose(1, 2),
+                                 torch.stack([WN[k].start.bias for k in ks])[:, None, :]], 1) for r, ks in runs])
+  w1x1 = torch.cat([pad(torch.stack([model.convinv[k].conv.weight.squeeze(2) for k in ks]), (0, 8 - r, 0, 8 - r))
+                    for r, ks in _shape_runs([model.convinv[k].conv.weight.shape[0] for k in range(nf)])])
   FL = nf * nl
   w_in = w_in.permute(0, 1, 3, 2).reshape(FL, 2 * Cc, 3 * Cc)                    # K = tap-major
   w1 = torch.cat([w_in, w_cond], 2)                                              # [FL, 2C, 3C + M8]
@@ -236,10 +241,16 @@ class _Weights:
     self.b2 = nat[3].float().contiguous()
     self.bup = nat[6].index_select(0, pm.m8).float()
     start5, out_init, w1x1 = nat[7].index_select(2, pm.c), nat[8], nat[9]
-    self.wstart = [start5[k, :flow_c[k] // 2].t().contiguous().float() for k in range(nf)]     # [C, h]
-    self.bstart = [start5[k, 4].contiguous().float() for k in range(nf)]
-    self.out_init = [out_init[k].contiguous().float() for k in range(nf)]
-    self.w1x1 = [w1x1[k, :flow_c[k], :flow_c[k]].contiguous().float() for k in range(nf)]
+    # per-flow operands as rows of one tensor per shape run (a copy per flow and operand was 48 tiny kernels per step)
+    self.wstart, self.w1x1 = [None] * nf, [None] * nf
+    for c, ks in _shape_runs(flow_c):
+      ws = start5[ks[0]:ks[-1] + 1, :c // 2].transpose(1, 2).float().contiguous()           # [n, C, h]
+      w1 = w1x1[ks[0]:ks[-1] + 1, :c, :c].float().contiguous()
+      for j, k in enumerate(ks):
+        self.wstart[k], self.w1x1[k] = ws[j], w1[j]
+    bst, oi = start5[:, 4].float().contiguous(), out_init.float().contiguous()
+    self.bstart = [bst[k] for k in range(nf)]
+    self.out_init = [oi[k] for k in range(nf)]
     arr = lambda ts: (C.c_void_p * nf)(*[t.data_ptr() for t in ts])
     self._arrs = [arr(self.wstart), arr(self.bstart), arr(self.out_init), arr(self.w1x1)]
     self.struct = _lib.WgTrainWeights(_ptr(self.a1), _ptr(self.a1c), _ptr(self.b1), _ptr(self.a2), _ptr(self.b2), _ptr(self.es),
@@ -449,7 +460,8 @@ class _TrainFn(torch.autograd.Function):
     # loss with another normalisation needs model.grad_scale) or inf / nan inputs: every gradient tensor is checked,
     # on the device.  model.grad_finite is read by waveglow_amd.training.train() before the optimiser step;
     # WG_TRAIN_CHECK_FINITE=1 raises here (one host sync per step).
-    model.grad_finite = torch.isfinite(bufs.flat).all()
+    # (one reduction: inf / nan anywhere makes the sum non-finite, and 8.6e7 finite fp32 values cannot overflow it)
+    model.grad_finite = torch.isfinite(bufs.flat.sum())
     if os.environ.get("WG_TRAIN_CHECK_FINITE") == "1" and not bool(model.grad_finite):
       raise _lib.WgError(nonfinite_message(ctx.scale))
     grads = bufs.packed_grads()
