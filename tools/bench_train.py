@@ -39,7 +39,7 @@ def main():
   opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True) if a.adam else None
   ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
   t_f = t_b = t_o = 0.0
-  wall = 0.0
+  wall = host = 0.0
   for it in range(a.warmup + a.steps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -53,15 +53,17 @@ def main():
     if opt is not None:
       opt.step()
     ev[3].record()
+    t_host = time.perf_counter() - t0            # everything queued; the device may still be busy
     torch.cuda.synchronize()
     if it >= a.warmup:
+      host += t_host
       wall += time.perf_counter() - t0
       t_f += ev[0].elapsed_time(ev[1]); t_b += ev[1].elapsed_time(ev[2]); t_o += ev[2].elapsed_time(ev[3])
   n = a.steps
   samples = a.batch * a.segment
   macs = 81235408 / 8 if a.channels == 256 else None    # forward MACs per sample
   out = {"workload": f"train step WaveGlow-{a.channels} batch {a.batch} x {a.segment} samples", "loss": float(loss.detach()),
-         "ms_forward": t_f / n, "ms_backward": t_b / n, "ms_optimizer": t_o / n, "ms_step_wall": 1e3 * wall / n,
+         "ms_forward": t_f / n, "ms_backward": t_b / n, "ms_optimizer": t_o / n, "ms_step_wall": 1e3 * wall / n, "ms_host_enqueue": 1e3 * host / n,
          "samples_per_s": samples / (wall / n), "mem_GiB": torch.cuda.max_memory_allocated() / 2**30}
   if macs:
     out["algorithmic_TFLOPs_fwd_plus_bwd"] = 3 * 2 * macs * samples / 1e12

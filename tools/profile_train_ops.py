@@ -42,3 +42,8 @@ rows = [e for e in ka if e.key in ("aten::copy_", "aten::clone", "aten::contiguo
 rows.sort(key=lambda e: -e.count)
 for e in rows[:60]:
   print("%5d %9.1f  %-22s %s" % (e.count, getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0.0)), e.key, str(e.input_shapes)[:150]))
+
+print("---- every op / kernel with >= 40 calls")
+for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.count):
+  if e.count >= 40:
+    print("%5d %9.1f  %-60s %s" % (e.count, getattr(e, "device_time_total", 0.0), e.key[:60], str(e.input_shapes)[:120]))

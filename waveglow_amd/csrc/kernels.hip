@@ -1334,7 +1334,10 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
   {
     const size_t row = row0 + tid;
     if (row < nrows) {
-      const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+      // 32-bit row arithmetic (launch_flow checks the range): a 64-bit division is ~150 instructions, and this kernel
+      // did 33 of them per thread -- it was ALU-bound on them, not HBM-bound
+      const unsigned r32 = (unsigned)row;
+      const int b = (int)(r32 / (unsigned)L), t = (int)(r32 - (unsigned)b * (unsigned)L);
       // ragged batch: columns behind an utterance's own length are padding -- their state is carried along (finite,
       // never read by a valid column) but they are never written into the x / a0 planes, and their audio is zero
       const bool pad_row = a.g.frames != nullptr && t >= 32 * a.g.frames[b];
@@ -1483,6 +1486,21 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
   // consecutive threads write consecutive bytes and a thread's g8 is fixed: its 8x4 weights sit in registers.
   const int C = a.C, h = a.h_next;
   const int g8 = tid & 7;
+  // plane rows of this thread's 8 rows (one per pass), once for all chunks: phase-major row of (b, t = 32q + p), see RowGeom
+  unsigned prow[8];
+  unsigned ok = 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int rl = it * (FL_ROWS / 8) + (tid >> 3);
+    const size_t row = row0 + rl;
+    prow[it] = 0;
+    if (row >= nrows) continue;
+    const unsigned r32 = (unsigned)row;
+    const int b = (int)(r32 / (unsigned)L), t = (int)(r32 - (unsigned)b * (unsigned)L);
+    if (a.g.frames != nullptr && t >= 32 * a.g.frames[b]) continue;      // padding column of a ragged batch
+    prow[it] = (unsigned)kRowPad + (unsigned)(t & 31) * (unsigned)a.g.Rp + (unsigned)b * (unsigned)a.g.Fp + (unsigned)a.g.Gf + (unsigned)(t >> 5);
+    ok |= 1u << it;
+  }
   for (int cc = 0; cc < C / 64; ++cc) {
     const int P0 = cc * 64 + g8 * 8;
     float w[8][4], bs[8];
@@ -1493,26 +1511,22 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
       for (int j = 0; j < 4; ++j) w[e][j] = (j < h) ? a.wstart[(P0 + e) * h + j] : 0.0f;
     }
 #pragma unroll
-    for (int it = 0; it < FL_ROWS * 8 / FL_ROWS; ++it) {
+    for (int it = 0; it < 8; ++it) {
+      if (!((ok >> it) & 1u)) continue;
       const int rl = it * (FL_ROWS / 8) + (tid >> 3);
-      const size_t row = row0 + rl;
-      if (row >= nrows) continue;
       const float4 a0 = s_a0[rl];
       half8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         o[e] = (_Float16)fmaf(w[e][3], a0.w, fmaf(w[e][2], a0.z, fmaf(w[e][1], a0.y, fmaf(w[e][0], a0.x, bs[e]))));
-      const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
-      if (a.g.frames != nullptr && t >= 32 * a.g.frames[b]) continue;     // padding column of a ragged batch
-      // phase-major plane row of (b, t = 32q + p), see RowGeom
-      const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
-      *(half8*)(a.x + ((size_t)cc * a.g.R + prow) * 64 + g8 * 8) = o;
+      *(half8*)(a.x + ((size_t)cc * a.g.R + prow[it]) * 64 + g8 * 8) = o;
     }
   }
 }
 
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s) {
   const size_t nrows = (size_t)a.g.B * a.g.L;
+  if (nrows >= (1ull << 31) || (size_t)a.g.R >= (1ull << 31)) return hipErrorInvalidValue;   // 32-bit row arithmetic in the kernel
   if (nrows < 256 * 256) {
     hipLaunchKernelGGL(flow_kernel<64>, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, s, a);
   } else {
