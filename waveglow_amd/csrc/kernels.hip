@@ -125,6 +125,14 @@ constexpr bool kPrio = true;
 // groups' loads: -0.5 %; the GEMM-2 weight fragments fetched inside the last K-step instead of phase 0 of the epilogue:
 // phase 0 -1.2 k cycles, K loop +0.9 k, +-0.1 % end to end; both waves' loads moved to different slots by branches inside
 // the load statements: the "+v" ties make hipcc copy fragment registers, and the K loop spills.)
+// The end x skip weight fragments of the pipelined epilogue go out one per two slots of phase NT-1 instead of as one
+// burst of 8 KiB per wave at its top (same-box A/B +0.5 %).  (The priority alternation in the backward dgrad variants:
+// no measurable change, left out.)
+#ifdef WG_NO_ES_SPREAD
+constexpr bool kEsSpread = false;     // A/B builds
+#else
+constexpr bool kEsSpread = true;
+#endif
 #ifdef WG_NO_DEEP
 constexpr bool kDeep = false;         // A/B builds: the one-step ring for small workloads too
 #else
@@ -715,10 +723,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     float4 es_o[NGRP];
     float4* es_op[NGRP];
     bool es_valid[NGRP];
-    auto es_prefetch = [&]() {
+    auto es_prefetch_w = [&](int s_) { wes[s_] = ((const half8*)a.wEs + laneo)[s_ * 64]; };
+    auto es_prefetch = [&](bool with_w = true) {
       const half8* pe = (const half8*)a.wEs + laneo;
+      if (with_w) {
 #pragma unroll
-      for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
+        for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
+      }
 #pragma unroll
       for (int gi = 0; gi < NGRP; ++gi) {
         const int grp = wave + gi * NW;
@@ -832,7 +843,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[1], xr[1], d2, 0, 0, 0);
         }
         if (do_mm && c < NT) load_xr(c);                      // residual of chunk c: phase c+1 starts from it
-        if (c == NT - 1) es_prefetch();                       // end x skip weights + out rows: consumed in the last phase
+        if (c == NT - 1) es_prefetch(!kEsSpread);             // end x skip weights + out rows: consumed in the last phase
         if (c == NT) es_compute();                            // every acts row is in LDS (barrier of phase NT-1)
         // gate pipeline state (static indices after unrolling)
         float e1[SL], den[SL], rc[SL];
@@ -887,6 +898,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if (has_k(i)) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2r[k_of(i)], bq[k_of(i)], d2, 0, 0, 0);
           }
           if (c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
+          if (kEsSpread && c == NT - 1 && (i & 1) && (i >> 1) < C / 32) es_prefetch_w(i >> 1);   // one weight fragment every other slot
           if (do_gate) {
             if (i + 2 < SL) stageA(i + 2);
             if (i + 1 < SL) stageB(i + 1);

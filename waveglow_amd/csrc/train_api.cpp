@@ -483,6 +483,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     const int f = atoi(e);
     if (f == 64 || (f == 128 && wn_block_n(C) == 128)) BNw = f;
   }
+  if (const char* e = getenv("WG_TRAIN_BWD_BN")) {      // A/B runs: tile width of the backward launches alone
+    const int f = atoi(e);
+    if (f == 64 || (f == 128 && wn_block_n(C) == 128)) BNw = f;
+  }
   // where entry fl of a per-layer gradient tensor lives: dense, or in interleaved per-layer records (wg_train_grads)
   if ((gr->layer_stride == 0) != (gr->flow_stride == 0) || gr->layer_stride < 0 || gr->flow_stride < 0)
     return wg_set_error(WG_ERR_INVALID, "wg_train_grads: layer_stride and flow_stride must both be 0 or both positive");
