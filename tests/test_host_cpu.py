@@ -410,3 +410,14 @@ def test_batched_log_det_w_equals_per_flow_logdet():
   g_want = torch.autograd.grad(sum(c * t for c, t in zip(coef, want)), [m.conv.weight for m in model.convinv])
   for a, b in zip(g_got, g_want):
     assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
+def test_shape_runs_keep_flow_order():
+  """waveglow_amd/train.py: _shape_runs -- the per-flow small tensors (end, start, 1x1; model.py:165-176: c_k drops at
+  the early outputs) are stacked per run of equal shape; concatenating the runs must give back flow order."""
+  from waveglow_amd.train import _shape_runs
+  assert _shape_runs([8, 8, 8, 8, 6, 6, 6, 6, 4, 4, 4, 4]) == [(8, [0, 1, 2, 3]), (6, [4, 5, 6, 7]), (4, [8, 9, 10, 11])]
+  assert _shape_runs([4]) == [(4, [0])]
+  runs = _shape_runs([8, 6, 8, 8])                  # a shape that comes back starts a new run: order is never permuted
+  assert runs == [(8, [0]), (6, [1]), (8, [2, 3])]
+  assert [k for _, ks in runs for k in ks] == [0, 1, 2, 3]

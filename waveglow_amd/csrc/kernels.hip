@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NAH = MT * 2;            // A fragments per half K-step (packing unit)
   constexpr bool DEFER = (MB == 1);      // defer a step's last sub-step past the barrier (needs spare registers)
   static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 1 && (NTAPS == 1 || NTAPS == 3), "tile geometry");
-  static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && NKX >= 4 && NKX % 2 == 0), "deep prefetch variant");
+  static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && ((NKX >= 4 && NKX % 2 == 0) || NKX == 3)), "deep prefetch variant");
   static_assert(MODE == 0 || (TPW == 1 && CX == (MODE == 2 ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -601,23 +601,34 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       using P1 = std::integral_constant<int, 1>;
       //        parity more  more2 ncond first
       kstep_d(P0{}, T_{}, T_{}, F_{}, T_{}, 0);
+      if constexpr (NKX == 3) {                                         // first layer of a WN: three a0-plane steps
+        kstep_d(P1{}, T_{}, T_{}, F_{}, F_{}, 1);
+        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, 2);                       // last tap step: the next B tile is a conditioning tile
+        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, 3);                       // five conditioning steps (the host checks n_cond_steps)
+        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, 4);
+        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, 5);
+        kstep_d(P0{}, T_{}, F_{}, T_{}, F_{}, 6);
+        kstep_d(P1{}, F_{}, F_{}, F_{}, F_{}, 7);
+      } else {
 #pragma clang loop unroll(disable)
-      for (int ks = 1; ks < NKX - 1; ks += 2) {                       // NKX even: pairs (odd, even)
-        kstep_d(P1{}, T_{}, T_{}, F_{}, F_{}, ks);
-        kstep_d(P0{}, T_{}, T_{}, F_{}, F_{}, ks + 1);
+        for (int ks = 1; ks < NKX - 1; ks += 2) {                       // NKX even: pairs (odd, even)
+          kstep_d(P1{}, T_{}, T_{}, F_{}, F_{}, ks);
+          kstep_d(P0{}, T_{}, T_{}, F_{}, F_{}, ks + 1);
+        }
+        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, NKX - 1);                 // last tap step: the next B tile is a conditioning tile
+        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, NKX);                     // five conditioning steps (the host checks n_cond_steps)
+        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, NKX + 1);
+        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, NKX + 2);
+        kstep_d(P1{}, T_{}, F_{}, T_{}, F_{}, NKX + 3);
+        kstep_d(P0{}, F_{}, F_{}, F_{}, F_{}, NKX + 4);
       }
-      kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, NKX - 1);                 // last tap step: the next B tile is a conditioning tile
-      kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, NKX);                     // five conditioning steps (the host checks n_cond_steps)
-      kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, NKX + 1);
-      kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, NKX + 2);
-      kstep_d(P1{}, T_{}, F_{}, T_{}, F_{}, NKX + 3);
-      kstep_d(P0{}, F_{}, F_{}, F_{}, F_{}, NKX + 4);
-      wait_vm<0>();                                                   // A(nK-1, 3)
+      constexpr int PL = (NKX + 4) & 1;                                 // ring of the last step
+      wait_vm<0>();                                                     // A(nK-1, 3)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Q[0][3][mt], bf[1][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Q[DEEP ? PL : 0][3][mt], bf[1][nt], acc[mt][nt], 0, 0, 0);
     }
     if constexpr (!DEEP) {
       using T_ = std::true_type;
@@ -1110,7 +1121,12 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
 }
 template <int C, int BN, bool HAS_RES, int TPW>
 static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
-  if (a.x_chunks_per_tap == 1) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
+  if (a.x_chunks_per_tap == 1) {
+    if constexpr (kDeep && C == 256 && BN == 64 && TPW == 1) {
+      if (a.n_cond_steps == 5) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1, 0, 3, true, true>(a, s);
+    }
+    return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
+  }
   // small workloads (one tile per workgroup, 64 columns) at 256 channels / 80 mel channels: two-step-deep weight prefetch
   if constexpr (kDeep && C == 256 && BN == 64 && TPW == 1) {
     if (a.n_cond_steps == 5) return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64, 0, 3, true, true>(a, s);
