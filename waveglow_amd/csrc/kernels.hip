@@ -450,9 +450,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     constexpr int GPS = (NG + NT - 1) / NT;      // LDS-DMA pieces per slot
     half8 bf[2][NT];
     // kPrio (see the knob): waves 4-7 hold the raised priority through the deferred sub-step and sub-step 0, waves 0-3
-    // through sub-steps 1 and 2; the switch sits inside the last slot of the sub-step before.  The training forward has it
-    // too; the first-layer variants (CX = 1) spill with it and go without.
-    constexpr bool PRIO = kPrio && NW == 8 && BN == 128 && ((MODE == 0 && CX == C / 64) || MODE == 1);
+    // through sub-steps 1 and 2; the switch sits inside the last slot of the sub-step before.  The training forward and the
+    // 512-channel kernel (+0.8 % at configs[2]) have it too; the first-layer variants (CX = 1) spill with it and go without.
+    constexpr bool PRIO = kPrio && NW == 8 && ((BN == 128 && ((MODE == 0 && CX == C / 64) || MODE == 1)) || (C == 512 && MODE == 0 && CX == C / 64));
     auto prio_set = [&](int hi_grp) {
       if (hi_grp == 1)
         asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 1\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 0\n.Lpb%=:" :: "s"(wave) : "memory", "scc");
