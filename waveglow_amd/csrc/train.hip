@@ -852,33 +852,71 @@ __global__ void __launch_bounds__(FB_ROWS) flow_bwd_post_kernel(const FlowBwdArg
   float gy[kMaxGroup], xin[kMaxGroup];
 #pragma unroll
   for (int j = 0; j < kMaxGroup; ++j) { gy[j] = 0.0f; xin[j] = 0.0f; }
+  // ---- d a0 += Wstart^T d x_0.  A thread owns one row, but a row's 512 bytes of d x_0 sit in four planes whose rows for
+  // consecutive t are far apart (phase-major): read per owner, every load instruction touched 64 different 128-byte lines
+  // for 16 bytes each (58 us per launch).  Now 8 lanes fetch one row's 128-byte line of a plane together, multiply their
+  // 8 channels by their rows of Wstart and the partial sums meet in LDS.
+  __shared__ unsigned s_prow[FB_ROWS];
+  __shared__ float s_wn[FB_ROWS][4];
+  int b = 0, t = 0;
+  {
+    unsigned pr = 0xffffffffu;
+    if (row < nrows) {
+      const unsigned r32 = (unsigned)row;
+      b = (int)(r32 / (unsigned)L);
+      t = (int)(r32 - (unsigned)b * (unsigned)L);
+      pr = (unsigned)kRowPad + (unsigned)(t & 31) * (unsigned)a.g.Rp + (unsigned)b * (unsigned)a.g.Fp + (unsigned)a.g.Gf + (unsigned)(t >> 5);
+    }
+    s_prow[threadIdx.x] = pr;
+  }
+  __syncthreads();
+  {
+    const int sub = threadIdx.x & 7, r8 = threadIdx.x >> 3;      // 16-byte piece of a row's line; row inside a pass of 32
+    float wacc[FB_ROWS / 32][4];
+#pragma unroll
+    for (int ps = 0; ps < FB_ROWS / 32; ++ps)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wacc[ps][j] = 0.0f;
+    for (int cc = 0; cc < a.C / 64; ++cc) {
+      float w[8][4];                                             // Wstart rows of this lane's 8 channels of the chunk
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[e][j] = (j < h) ? a.wstart[(cc * 64 + sub * 8 + e) * h + j] : 0.0f;
+#pragma unroll
+      for (int ps = 0; ps < FB_ROWS / 32; ++ps) {
+        const unsigned pr = s_prow[ps * 32 + r8];
+        if (pr == 0xffffffffu) continue;
+        const half8 x = *(const half8*)(a.GX + ((size_t)cc * a.g.R + pr) * 64 + sub * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = (float)x[e];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wacc[ps][j] = fmaf(w[e][j], xv, wacc[ps][j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < FB_ROWS / 32; ++ps)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = wacc[ps][j];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        if (sub == 0) s_wn[ps * 32 + r8][j] = v;
+      }
+  }
+  __syncthreads();
   if (row < nrows) {
-    const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
-    const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
     {
       const float4* gp = (const float4*)(a.GZ + row * 8);
       const float4 g0 = gp[0], g1 = gp[1];
       gy[0] = g0.x; gy[1] = g0.y; gy[2] = g0.z; gy[3] = g0.w; gy[4] = g1.x; gy[5] = g1.y; gy[6] = g1.z; gy[7] = g1.w;
     }
-    float wn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int cc = 0; cc < a.C / 64; ++cc) {
-      const half8* xp = (const half8*)(a.GX + ((size_t)cc * a.g.R + prow) * 64);
-#pragma unroll
-      for (int v8 = 0; v8 < 8; ++v8) {
-        const half8 x = xp[v8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int P = cc * 64 + v8 * 8 + e;
-          const float xv = (float)x[e];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < h) wn[j] = fmaf(a.wstart[P * h + j], xv, wn[j]);
-        }
-      }
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < h) gy[j] += wn[j];
+      if (j < h) gy[j] += s_wn[threadIdx.x][j];
     // input of this flow's 1x1 conv
     if (a.Zprev) {
       const float4* zp = (const float4*)(a.Zprev + row * 8);
