@@ -141,6 +141,13 @@ constexpr bool kQ2Late = false;       // A/B builds
 #else
 constexpr bool kQ2Late = true;
 #endif
+// DEEP rings: quarter 2 of step ks+1 is fetched in the last slot of step ks's deferred sub-step (its ring slot was freed in
+// sub-step 2 of step ks-1) instead of as two uncovered loads at the end of step ks-1 (-0.3 % on configs[0], same-box).
+#ifdef WG_NO_DEEP_Q2
+constexpr bool kDeepQ2 = false;       // A/B builds
+#else
+constexpr bool kDeepQ2 = true;
+#endif
 #ifdef WG_NO_DEEP
 constexpr bool kDeep = false;         // A/B builds: the one-step ring for small workloads too
 #else
@@ -384,7 +391,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, Q[0][g][mt]);
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+      for (int g = 0; g < (kDeepQ2 ? 2 : 3); ++g)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) load_Aq(1, g, mt, Q[DEEP ? 1 : 0][g][mt]);
     } else {
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     // VMEM issue order per step: DMA xNG, q2 xMT, q3 xMT, q0 xMT, q1 xMT -- every wait is a counted vmcnt.
     // The first and last steps are peeled and "next step is a conditioning step" is a compile-time flag, so the
     // loop bodies are branch-free.
-    wait_vm<DEEP ? 4 * MT : 0>();                // DEEP: A(0, 3) and A(1, .) may still be in flight (steady-state invariant)
+    wait_vm<DEEP ? (kDeepQ2 ? 3 : 4) * MT : 0>();   // DEEP: A(0, 3) and A(1, .) may still be in flight (steady-state invariant)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     WG_STAMP(1);
@@ -550,9 +557,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // ---- DEEP K-step.  VMEM issue order per step: DMA(ks+1) x NG, A(ks+1, 3) x MT, A(ks+2, 0), A(ks+2, 1), A(ks+2, 2);
-    // the wait in front of the barrier -- at most A(ks+1, 3) and A(ks+2, .) outstanding -- covers the B tile and every
-    // fragment step ks+1 uses.  P = parity of ks; sub-step 3 of step ks-1 (ring P^1) is the deferred one.
+    // ---- DEEP K-step.  VMEM issue order per step: DMA(ks+1) x NG, A(ks+1, 2) x MT, A(ks+1, 3) x MT, A(ks+2, 0), A(ks+2, 1);
+    // the wait in front of the barrier -- at most A(ks+1, 3), A(ks+2, 0) and A(ks+2, 1) outstanding -- covers the B tile and
+    // every fragment step ks+1 uses.  P = parity of ks; sub-step 3 of step ks-1 (ring P^1) is the deferred one.
     auto kstep_d = [&](auto par_tag, auto more_tag, auto more2_tag, auto ncond_tag, auto first_tag, int ks) {
       constexpr int P = DEEP ? decltype(par_tag)::value : 0, PO = DEEP ? 1 - P : 0;
       constexpr bool more = decltype(more_tag)::value, more2 = decltype(more2_tag)::value;
@@ -578,6 +585,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if constexpr (ncond) glds16(a.melT, cond_voff(ks + 1 - NKX, nt), lds);
             else glds16(src_next, pvoff[nt], lds);
           }
+          if constexpr (kDeepQ2) {            // quarter 2 of the NEXT step (its ring slot was freed in sub-step 2 of step ks-1)
+            if (nt == NT - 1) {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 1, 2, mt, Q[PO][2][mt]);
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -597,12 +610,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if constexpr (more2) {
+      if constexpr (more2 && !kDeepQ2) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 2, 2, mt, Q[P][2][mt]);
       }
       if constexpr (more) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(more2 ? 4 * MT : MT) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(more2 ? (kDeepQ2 ? 3 : 4) * MT : MT) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
