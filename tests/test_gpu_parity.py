@@ -537,6 +537,28 @@ def test_infer_graph_replay_matches_direct_launch():
   assert torch.equal(a, b)
 
 
+def test_deep_prefetch_kernel_equals_one_step_ring(monkeypatch):
+  """Small workloads at 256 channels / 80 mel channels run the two-step-deep weight-prefetch variant of wn_layer_kernel
+  (hand-counted waits of its own, both for the regular and the first-layer K loops): same MFMA order, so it must agree BIT
+  FOR BIT with the one-step ring (WG_DISABLE_DEEP=1, read per launch).  A wrong vmcnt or ring index shows up here first."""
+  hp = HParams()                                     # 256 channels, 12 flows, 8 layers
+  sd = synthetic.make_state_dict(hp, seed=6)
+  model = build_model(hp, sd)
+  for B, T in ((1, 40), (1, 131), (2, 37)):
+    mel = synthetic.make_mel(B, T, seed=T).cuda()
+    z_init, z_early = synthetic.make_noise(hp, B, 32 * T, seed=100 + T)
+    ze = [z_early[k].cuda() for k in sorted(z_early, reverse=True)]
+    with torch.no_grad():
+      monkeypatch.delenv("WG_DISABLE_DEEP", raising=False)
+      deep = model.infer_with_noise(mel, z_init.cuda(), ze, 0.6)
+      monkeypatch.setenv("WG_DISABLE_DEEP", "1")
+      ring = model.infer_with_noise(mel, z_init.cuda(), ze, 0.6)
+    torch.cuda.synchronize()
+    assert torch.isfinite(deep).all() and float(deep.abs().max()) > 1e-3
+    assert torch.equal(deep, ring), (B, T, float((deep - ring).abs().max()))
+  monkeypatch.delenv("WG_DISABLE_DEEP", raising=False)
+
+
 def test_infer_configs0_shape_against_reference_summary():
   """BASELINE configs[0] (256 channels, mel [1,80,500] -> 128 000 samples, fp32): summary fixture written by the
   reference's own ``WaveGlow.infer`` (tests/golden/make_golden_cfg1.py).  The noise is the reference's: its three
