@@ -126,14 +126,6 @@ constexpr bool kPrio = true;
 // groups' loads: -0.5 %; the GEMM-2 weight fragments fetched inside the last K-step instead of phase 0 of the epilogue:
 // phase 0 -1.2 k cycles, K loop +0.9 k, +-0.1 % end to end; both waves' loads moved to different slots by branches inside
 // the load statements: the "+v" ties make hipcc copy fragment registers, and the K loop spills.)
-// The end x skip weight fragments of the pipelined epilogue go out one per two slots of phase NT-1 instead of as one
-// burst of 8 KiB per wave at its top (same-box A/B +0.5 %).  (The priority alternation in the backward dgrad variants:
-// no measurable change, left out.)
-#ifdef WG_NO_ES_SPREAD
-constexpr bool kEsSpread = false;     // A/B builds
-#else
-constexpr bool kEsSpread = true;
-#endif
 // q[2] of a K-step is fetched in the load-free slots of the step's own deferred sub-step (behind the DMA pieces) instead of
 // as two loads back to back at the end of the step before, where nothing covers their issue; the step then ends with the
 // counted wait and the barrier alone.  Same-box A/B +0.25 % (0.6143 -> 0.6158), training neutral.
@@ -148,6 +140,16 @@ constexpr bool kQ2Late = true;
 constexpr bool kDeepQ2 = false;       // A/B builds
 #else
 constexpr bool kDeepQ2 = true;
+#endif
+// The folded end x skip weight fragments (hi + lo rows, C/32 KiB) are the same for every wave and every tile of a launch:
+// they are staged in LDS once per workgroup and read from there right before their MFMAs, instead of C/32 global 1-KiB
+// loads per wave and tile (8 x redundant through the vector memory path).  Same-box A/B: fetching them one per two slots
+// of the second-to-last phase instead of as a burst gave +0.5 %, the LDS copy another +0.25 % (0.6180 -> 0.6195).
+// (The priority alternation in the backward dgrad variants: no measurable change, left out.)
+#ifdef WG_NO_WES_LDS
+constexpr bool kWesLds = false;       // A/B builds: global loads at the top of the second-to-last phase
+#else
+constexpr bool kWesLds = true;
 #endif
 #ifdef WG_NO_DEEP
 constexpr bool kDeep = false;         // A/B builds: the one-step ring for small workloads too
@@ -364,6 +366,10 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     for (int i = tid; i < 2 * C; i += NTHREADS) sBias[i] = a.bias1[i];
     if constexpr (HAS_RES)
       for (int i = tid; i < C; i += NTHREADS) sBias[2 * C + i] = a.bias2[i];   // b_res, read by the pipelined epilogue
+    if constexpr (kWesLds) {
+      uint4* const sW = (uint4*)(sBias + 3 * C);                 // [C/32][64 lanes] x 16 B, behind the biases
+      for (int i = tid; i < (C / 32) * 64; i += NTHREADS) sW[i] = ((const uint4*)a.wEs)[i];
+    }
   }
   __syncthreads();
 
@@ -761,10 +767,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     float4 es_o[NGRP];
     float4* es_op[NGRP];
     bool es_valid[NGRP];
-    auto es_prefetch_w = [&](int s_) { wes[s_] = ((const half8*)a.wEs + laneo)[s_ * 64]; };
+    auto es_prefetch_w = [&](int s_) {
+      if constexpr (kWesLds) wes[s_] = ((const half8*)(sBias + 3 * C) + laneo)[s_ * 64];
+      else wes[s_] = ((const half8*)a.wEs + laneo)[s_ * 64];
+    };
     auto es_prefetch = [&](bool with_w = true) {
       const half8* pe = (const half8*)a.wEs + laneo;
-      if (with_w) {
+      if (with_w && !kWesLds) {
 #pragma unroll
         for (int s = 0; s < C / 32; ++s) wes[s] = pe[s * 64];
       }
@@ -783,6 +792,10 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
     };
     auto es_compute = [&]() {
+      if constexpr (kWesLds) {
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) es_prefetch_w(s);
+      }
 #pragma unroll
       for (int gi = 0; gi < NGRP; ++gi) {
         const int grp = wave + gi * NW;
@@ -881,7 +894,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
           d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[1], xr[1], d2, 0, 0, 0);
         }
         if (do_mm && c < NT) load_xr(c);                      // residual of chunk c: phase c+1 starts from it
-        if (c == NT - 1) es_prefetch(!kEsSpread);             // end x skip weights + out rows: consumed in the last phase
+        if (c == NT - 1) es_prefetch();                       // end x skip out rows (and weights, without kWesLds): consumed in the last phase
         if (c == NT) es_compute();                            // every acts row is in LDS (barrier of phase NT-1)
         // gate pipeline state (static indices after unrolling)
         float e1[SL], den[SL], rc[SL];
@@ -936,7 +949,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if (has_k(i)) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2r[k_of(i)], bq[k_of(i)], d2, 0, 0, 0);
           }
           if (c == 0 && i < K2) a2r[i] = p2[(size_t)i * 64];
-          if (kEsSpread && c == NT - 1 && (i & 1) && (i >> 1) < C / 32) es_prefetch_w(i >> 1);   // one weight fragment every other slot
           if (do_gate) {
             if (i + 2 < SL) stageA(i + 2);
             if (i + 1 < SL) stageB(i + 1);
@@ -1132,7 +1144,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
-  constexpr int smem = 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4);
+  constexpr int smem = 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP>,
