@@ -76,21 +76,42 @@ def pmc_traffic_bytes(args):
     return None
 
 
-def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
+def _cpu_budget():
+  """(affinity cores, cgroup CPU quota in cores or None): what this process may run on."""
+  try:
+    aff = len(os.sched_getaffinity(0))
+  except AttributeError:
+    aff = os.cpu_count() or 1
+  quota = None
+  try:
+    q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    if q != "max":
+      quota = float(q) / float(per)
+  except Exception:
+    try:
+      q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+      per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+      if q > 0:
+        quota = q / per
+    except Exception:
+      pass
+  return aff, quota
+
+
+def cpu_baseline(hp, sd, seconds_hint: float = 30.0):
   """The CPU oracle (port of the reference's fp32 infer, verified bit-equal to the reference in the build
-  container) timed on this host's cores on a bounded sample: configs[0] shape, mel [1,80,500]."""
+  container) timed on this host's cores at BASELINE configs[0]: mel [1,80,500], sigma 0.6.
+
+  The reference CLI uses every core it sees (set_torch_thread_to_max, src/waveglow/utils.py:27-29).  On a GPU box the
+  affinity mask can be far wider than the container's CPU quota (and the oneDNN/OpenMP pool then thrashes), so the
+  thread count is PROBED: T = 64 at a few candidate counts, the fastest is kept.  T = 500 is then timed once if the
+  probe predicts that it fits the budget; otherwise the largest T that does (said in `sample`)."""
   from oracle import torch_oracle as O
   from waveglow_amd import synthetic
   sys.path.insert(0, os.path.join(ROOT, "tests"))
   from _cases import oracle_cfg_from_hp
-  # reference CLI uses every core (set_torch_thread_to_max, src/waveglow/utils.py:27-29); here: the cores this
-  # process may actually run on, capped at the GPU box's per-GPU share of 16
-  try:
-    cores = len(os.sched_getaffinity(0))
-  except AttributeError:
-    cores = os.cpu_count() or 1
-  cores = max(1, min(cores, 16))
-  torch.set_num_threads(cores)
+  aff, quota = _cpu_budget()
+  cap = aff if quota is None else max(1, min(aff, int(round(quota))))
   cfg = oracle_cfg_from_hp(hp)
 
   def run(T):
@@ -101,28 +122,34 @@ def cpu_baseline(hp, sd, seconds_hint: float = 20.0):
       O.infer_ref(sd, mel, z_init, z_early, 0.6, cfg)
     return time.perf_counter() - t0
 
-  run(10)                        # warm-up (thread pool, oneDNN primitive caches)
-  # Run time grows much faster than linearly in T on the GPU box's host (T = 256 -> 500 measured 3 s -> 88 s: the
-  # [4096, 32T] cond tensor falls out of cache), so the sample is bounded at T = 256 and doubling stops as soon as
-  # the next run is not predicted to fit the budget.
-  T, best, spent = 32, None, 0.0
-  while True:
-    dt = run(T)
-    spent += dt
-    best = dt
-    if T >= 256 or dt * 3.0 + spent > seconds_hint:
+  cands = sorted({c for c in (4, 8, 16, 32, cap) if 1 <= c <= max(cap, 1)} | {min(cap, 8)})
+  probe, spent = {}, 0.0
+  for c in cands:
+    torch.set_num_threads(c)
+    run(8)                        # warm-up (thread pool, oneDNN primitive caches)
+    dt = min(run(64), run(64))
+    probe[c] = round(dt, 3)
+    spent += 2 * dt
+    if spent > 0.4 * seconds_hint:
       break
-    T = min(256, T * 2)
-  # spend the rest of a ~10 s budget on repeats of the final size and report the best of them
+  cores = min(probe, key=probe.get)
+  torch.set_num_threads(cores)
+  # the run time is close to linear in T once the thread count is right (T = 64 -> 500: x7.8 + a margin)
+  T = 500
+  while T > 64 and probe[cores] * (T / 64.0) * 1.3 > seconds_hint:
+    T //= 2
+  best = run(T)
+  spent += best
   reps = 1
-  while spent + best < 0.5 * seconds_hint and reps < 8:
+  while spent + best < seconds_hint and reps < 3:
     dt = run(T)
     spent += dt
     best = min(best, dt)
     reps += 1
   return {"value": round(256 * T / best, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-          "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}] (configs[0] is T=500), sigma 0.6, best of {reps} runs: "
-                    f"{best:.2f} s ({spent:.1f} s of CPU work in all)"}
+          "sample": f"oracle/torch_oracle.infer_ref fp32, mel [1,80,{T}]" + (" = configs[0]" if T == 500 else " (configs[0] is T=500)") +
+                    f", sigma 0.6, best of {reps} runs: {best:.2f} s ({spent:.1f} s of CPU work in all)",
+          "threads_probe_s_at_T64": probe, "affinity_cores": aff, "cgroup_quota_cores": quota}
 
 
 def train_roofline(hp, B, S, steps, ms, cnt, overlapped_ms_per_step=None):
@@ -148,19 +175,18 @@ def train_roofline(hp, B, S, steps, ms, cnt, overlapped_ms_per_step=None):
           "overlapped_ms_per_step": overlapped_ms_per_step}
 
 
-def bench_train(args, rank, world, dev, dist):
+def run_train(channels, B, S, steps, warmup, rank, world, dev, dist):
   """BASELINE configs[3]: the training step of src/waveglow/train.py:190-199 (forward, WaveGlowLoss, backward, Adam),
-  data-parallel: per-GPU batch fixed (weak scaling), gradients averaged by one bucketed all-reduce per step."""
+  data-parallel: per-GPU batch fixed (weak scaling), gradients averaged by one all-reduce per flow inside backward().
+  Returns the result dict (every rank; the times are the max over ranks)."""
   from waveglow_amd import synthetic
   from waveglow_amd.distributed import GradientAllReducer
   from waveglow_amd.hparams import HParams
   from waveglow_amd.model import WaveGlow, WaveGlowLoss
-  hp = HParams(n_channels=args.channels)
+  hp = HParams(n_channels=channels)
   model = WaveGlow(hp)
   model.load_state_dict(synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=0)))
   model = model.to(dev).train()
-  B = args.batch if args.batch != 16 else 32
-  S = args.segment
   F_ = 1 + S // 256
   mel = synthetic.make_mel(B, F_, seed=77 + rank).to(dev)
   g = torch.Generator().manual_seed(5 + rank)
@@ -168,8 +194,9 @@ def bench_train(args, rank, world, dev, dist):
   crit = WaveGlowLoss(1.0)
   opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)     # train.py:58-66; fused as in waveglow_amd/training.py:load_optimizer
   from waveglow_amd.train import enable_data_parallel
-  fused = enable_data_parallel(model)                     # all-reduce inside backward(), overlapped, when world > 1
-  red = None if fused else GradientAllReducer(model.parameters())
+  # all-reduce inside backward(), flow by flow, overlapped (world > 1; WG_BENCH_FORCE_DIST: also in a one-rank RCCL group)
+  fused = enable_data_parallel(model, force=bool(os.environ.get("WG_BENCH_FORCE_DIST"))) if dist is not None else False
+  red = None if (fused or dist is None) else GradientAllReducer(model.parameters())
 
   def step():
     opt.zero_grad(set_to_none=True)
@@ -180,59 +207,148 @@ def bench_train(args, rank, world, dev, dist):
     opt.step()
     return loss
 
-  for _ in range(args.warmup):
+  for _ in range(warmup):
     loss = step()
   eng = model._engine
-  eng.lib.wg_profile_enable(eng.handle, 1 << 6)  # hipEvents around the wgrad launches only (one pair per launch), on their stream
   torch.cuda.synchronize(dev)
   if dist is not None:
     dist.barrier()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  for _ in range(steps):
     loss = step()
   torch.cuda.synchronize(dev)
   if dist is not None:
     dist.barrier()
   elapsed = time.perf_counter() - t0
   assert torch.isfinite(loss.detach()).all()
+  # Kernel timing is taken AFTER the timed region (profiling records ~200 hipEvents per step on the weight-gradient
+  # stream): first as the step runs (streams overlapped), then with every launch on one stream (the kernel on its own).
   ms = (C.c_double * 8)()
   cnt = (C.c_int64 * 8)()
-  eng.lib.wg_profile_read(eng.handle, ms, cnt, 8)
-  overlapped = round(ms[6] / args.steps, 3)
-  # the kernel on its own: a few more steps with every launch on one stream (not part of `value`)
-  prof_steps = min(3, args.steps)
-  os.environ["WG_TRAIN_SERIAL"] = "1"
-  step()
-  torch.cuda.synchronize(dev)
-  eng.lib.wg_profile_enable(eng.handle, 1 << 6)
+  prof_steps = min(3, steps)
+  eng.lib.wg_profile_enable(eng.handle, 1 << 6)  # hipEvents around the wgrad launches only (one pair per launch), on their stream
   for _ in range(prof_steps):
     step()
   torch.cuda.synchronize(dev)
   eng.lib.wg_profile_read(eng.handle, ms, cnt, 8)
-  eng.lib.wg_profile_enable(eng.handle, 0)
-  del os.environ["WG_TRAIN_SERIAL"]
+  overlapped = round(ms[6] / prof_steps, 3)
+  os.environ["WG_TRAIN_SERIAL"] = "1"
+  try:
+    eng.lib.wg_profile_enable(eng.handle, 0)
+    step()
+    torch.cuda.synchronize(dev)
+    eng.lib.wg_profile_enable(eng.handle, (1 << 4) | (1 << 5) | (1 << 6))
+    for _ in range(prof_steps):
+      step()
+    torch.cuda.synchronize(dev)
+    eng.lib.wg_profile_read(eng.handle, ms, cnt, 8)
+    eng.lib.wg_profile_enable(eng.handle, 0)
+  finally:
+    del os.environ["WG_TRAIN_SERIAL"]
   if dist is not None:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-  if rank == 0:
-    samples = B * S * world
-    flops = 3 * 2.0 * (81235408 / 8 if args.channels == 256 else 261355984 / 8) * samples   # fwd + 2x bwd, SURVEY 8d
-    print(json.dumps({
-      "metric": "training samples/sec (WaveGlow-256 train step: forward + loss + backward + all-reduce + Adam)",
-      "value": round(samples * args.steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-      "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-      "scaling": "weak", "vs_baseline": None,
-      "dtype": "f16 MFMA operands / saved activations / gradient planes, f32 accumulate, f32 weights + Adam",
-      "data": "synthetic (random mels + uniform audio, random-init weight-normed parameters)",
-      "config": {"workload": f"configs[3]: {args.channels}ch train step, batch={B}/GPU x {S} samples, {F_} mel frames",
-                 "parallelism": f"dp{world}, per-flow gradient all-reduce (RCCL) overlapped with backward"},
-      "loss": float(loss.detach()),
-      "algorithmic_TFLOP_per_s": round(flops * args.steps / elapsed / 1e12, 1),
-      "roofline": train_roofline(hp, B, S, prof_steps, ms, cnt, overlapped)}), flush=True)
+  samples = B * S * world
+  flops = 3 * 2.0 * (81235408 / 8 if channels == 256 else 261355984 / 8) * samples   # fwd + 2x bwd, SURVEY 8d
+  roof = train_roofline(hp, B, S, prof_steps, ms, cnt, overlapped)
+  roof["kernel_ms_per_step"].update({"wn_layer_forward": round(ms[4] / prof_steps, 3), "dgrad": round(ms[5] / prof_steps, 3)})
+  out = {
+    "metric": "training samples/sec (WaveGlow-256 train step: forward + loss + backward + all-reduce + Adam)",
+    "value": round(samples * steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": steps,
+    "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+    "scaling": "weak", "vs_baseline": None,
+    "dtype": "f16 MFMA operands / saved activations / gradient planes, f32 accumulate, f32 weights + Adam",
+    "data": "synthetic (random mels + uniform audio, random-init weight-normed parameters)",
+    "config": {"workload": f"configs[3]: {channels}ch train step, batch={B}/GPU x {S} samples, {F_} mel frames",
+               "parallelism": f"dp{world}, per-flow gradient all-reduce (RCCL) overlapped with backward"},
+    "loss": float(loss.detach()),
+    "algorithmic_TFLOP_per_s": round(flops * steps / elapsed / 1e12, 1),
+    "roofline": roof}
+  del model, opt, eng
+  torch.cuda.empty_cache()
+  return out
+
+
+def build_infer_model(channels, dev):
+  from waveglow_amd import synthetic
+  from waveglow_amd.hparams import HParams
+  from waveglow_amd.model import WaveGlow
+  hp = HParams(n_channels=channels)
+  sd = synthetic.make_state_dict(hp, seed=0)
+  model = WaveGlow.remove_weightnorm(WaveGlow(hp))
+  model.load_state_dict(sd)
+  return hp, sd, model.to(dev).eval()
+
+
+def run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist):
+  """`steps` timed WaveGlow.infer calls (noise draws included) on one batch resident in HBM; returns
+  (elapsed seconds: max over ranks, per-class kernel ms, launch counts)."""
+  from waveglow_amd import synthetic
+  dtype = torch.float16 if dtype_name == "fp16" else torch.float32
+  mel = synthetic.make_mel(B, T, seed=1234 + rank).to(dev, dtype)
+  sigma = 0.6
+  torch.manual_seed(4321 + rank)
+  with torch.no_grad():
+    for _ in range(warmup):
+      audio = model.infer(mel, sigma=sigma)
+    eng = model._engine
+    eng.lib.wg_profile_enable(eng.handle, 1)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+      dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      audio = model.infer(mel, sigma=sigma)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+      dist.barrier()
+    elapsed = time.perf_counter() - t0
+  assert torch.isfinite(audio).all()
+  ms = (C.c_double * 4)()
+  cnt = (C.c_int64 * 4)()
+  eng.lib.wg_profile_read(eng.handle, ms, cnt, 4)
+  eng.lib.wg_profile_enable(eng.handle, 0)
   if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  return elapsed, list(ms), list(cnt)
+
+
+def infer_roofline(hp, B, T, steps, ms, cnt, traffic=None):
+  n_wn = int(cnt[2])
+  avg_wn_ms = ms[2] / max(1, n_wn)
+  launches_per_step = hp.n_flows * hp.n_layers
+  flops_per_launch = 2.0 * wn_layer_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
+  achieved = flops_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
+  executed_per_launch = 2.0 * wn_layer_executed_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
+  executed = executed_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
+  return {"bound": "mfma", "kernel": "wn_layer_kernel", "achieved": round(achieved, 2),
+          "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4),
+          "traffic": traffic, "avg_launch_ms": round(avg_wn_ms, 4), "launches_timed": n_wn,
+          "algorithmic_flops_per_launch": flops_per_launch,
+          # what the matrix cores actually execute after the weight folds (fewer MACs for the same result)
+          "executed_flops_per_launch": executed_per_launch, "executed_achieved": round(executed, 2),
+          "executed_frac": round(executed / PEAK_FP16_DENSE_TFLOPS, 4),
+          "kernel_ms_per_step": {"mel_pack": round(ms[0] / steps, 3), "flow_start": round(ms[1] / steps, 3),
+                                 "wn_layer": round(ms[2] / steps, 3), "memset": round(ms[3] / steps, 3)}}
+
+
+def secondary_infer(label, hp, model, B, T, dtype_name, steps, warmup, rank, world, dev, dist):
+  """One more BASELINE config, after the headline's timed region: the same measurement, condensed."""
+  elapsed, ms, cnt = run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist)
+  roof = infer_roofline(hp, B, T, steps, ms, cnt)
+  samples = B * T * 256 * world
+  flops_per_sample = 2.0 * (81235408 if hp.n_channels == 256 else 261355984) / 8 if hp.n_channels in (256, 512) else None
+  out = {"workload": label, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+         "samples_per_s": round(samples * steps / elapsed, 1),
+         "real_time_factor": round(samples * steps / elapsed / 22050.0, 1),
+         "frac": roof["frac"], "executed_frac": roof["executed_frac"], "wn_layer_avg_launch_ms": roof["avg_launch_ms"],
+         "wn_layer_ms_per_step": roof["kernel_ms_per_step"]["wn_layer"]}
+  if flops_per_sample:
+    out["whole_step_frac"] = round(flops_per_sample * samples * steps / elapsed / 1e12 / PEAK_FP16_DENSE_TFLOPS / world, 4)
+  return out
 
 
 def main():
@@ -245,6 +361,9 @@ def main():
   ap.add_argument("--channels", type=int, default=256)
   ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-secondary", action="store_true",
+                  help="skip the other BASELINE configs (configs[0], [2], [3], [4]) that the default run measures after the "
+                       "headline's timed region and reports under `secondary`")
   ap.add_argument("--workload", default="infer", choices=["infer", "train"],
                   help="infer: BASELINE configs[1] (the headline metric, default); train: configs[3], one optimiser step "
                        "(forward + loss + backward + gradient all-reduce + Adam) on batch 32 x 16000 samples per GPU")
@@ -264,95 +383,78 @@ def main():
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=dev)
 
-  from waveglow_amd import synthetic
-  from waveglow_amd.hparams import HParams
-  from waveglow_amd.model import WaveGlow
+  def finish():
+    if dist is not None:
+      dist.barrier()
+      dist.destroy_process_group()
 
   if args.workload == "train":
-    return bench_train(args, rank, world, dev, dist)
+    out = run_train(args.channels, args.batch if args.batch != 16 else 32, args.segment, args.steps, args.warmup,
+                    rank, world, dev, dist)
+    if rank == 0:
+      print(json.dumps(out), flush=True)
+    return finish()
 
-  hp = HParams(n_channels=args.channels)
-  sd = synthetic.make_state_dict(hp, seed=0)
-  model = WaveGlow.remove_weightnorm(WaveGlow(hp))
-  model.load_state_dict(sd)
-  dtype = torch.float16 if args.dtype == "fp16" else torch.float32
-  model = model.to(dev).eval()
+  hp, sd, model = build_infer_model(args.channels, dev)
   B, T = args.batch, args.frames
-  mel = synthetic.make_mel(B, T, seed=1234 + rank).to(dev, dtype)
-  sigma = 0.6
-  torch.manual_seed(4321 + rank)
+  elapsed, ms, cnt = run_infer(hp, model, B, T, args.dtype, args.steps, args.warmup, rank, dev, dist)
 
-  with torch.no_grad():
-    for _ in range(args.warmup):
-      audio = model.infer(mel, sigma=sigma)
-    eng = model._engine
-    eng.lib.wg_profile_enable(eng.handle, 1)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-      dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      audio = model.infer(mel, sigma=sigma)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-      dist.barrier()
-    elapsed = time.perf_counter() - t0
-  assert torch.isfinite(audio).all()
+  samples_per_step = B * T * 256 * world
+  value = samples_per_step * args.steps / elapsed
+  out = {
+    "metric": "audio samples/sec/GPU (22.05 kHz) WaveGlow-256 infer; real-time factor",
+    "value": round(value, 1),
+    "unit": "samples/s",
+    "n_gpus": world,
+    "steps": args.steps,
+    "warmup": args.warmup,
+    "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+    "higher_is_better": True,
+    "scaling": "weak",
+    "vs_baseline": None,
+    "dtype": "f16 MFMA operands, f32 accumulate/flow state, %s I/O" % args.dtype,
+    "data": "synthetic (random 80xT log-mels, synthetic weights of the LJS-v3 256ch architecture)",
+    "config": {"workload": f"{workload_label(args)}: {args.channels}ch WaveGlow.infer, batch={B}/GPU mels 80x{T}, "
+                           f"{args.dtype} I/O, sigma=0.6",
+               "per_gpu_samples_per_step": B * T * 256, "parallelism": f"utterance-sharded x{world}, no collective"},
+    "real_time_factor": round(value / 22050.0, 1),
+    "samples_per_s_per_gpu": round(value / world, 1),
+    "roofline": infer_roofline(hp, B, T, args.steps, ms, cnt, pmc_traffic_bytes(args)),
+  }
 
-  ms = (C.c_double * 4)()
-  cnt = (C.c_int64 * 4)()
-  eng.lib.wg_profile_read(eng.handle, ms, cnt, 4)
-  eng.lib.wg_profile_enable(eng.handle, 0)
-
-  if dist is not None:
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  # ---- the other BASELINE configs, each after the headline's timed region, in the SAME JSON line (`secondary`).
+  # Every rank runs them (utterance shards: no collective; the training step all-reduces its gradients over RCCL).
+  if not args.no_secondary and workload_label(args) == "configs[1]":
+    sec = {}
+    t_sec = time.perf_counter()
+    try:
+      sec["configs0"] = secondary_infer("configs[0]: 256ch, 1 mel 80x500, fp32 I/O (single-utterance latency, direct launches)",
+                                        hp, model, 1, 500, "fp32", 20, 5, rank, world, dev, dist)
+      sec["configs4_shard"] = secondary_infer("configs[4]: 256ch, one GPU's shard = 32 mels 80x4000, fp16 I/O",
+                                              hp, model, 32, 4000, "fp16", 3, 1, rank, world, dev, dist)
+      del model
+      torch.cuda.empty_cache()
+      hp5, _sd5, model5 = build_infer_model(512, dev)
+      sec["configs2"] = secondary_infer("configs[2]: 512ch / 12 flows / 8 layers, 64 mels 80x864, fp16 I/O",
+                                        hp5, model5, 64, 864, "fp16", 3, 1, rank, world, dev, dist)
+      del model5, _sd5
+      torch.cuda.empty_cache()
+      tr = run_train(256, 32, 16000, 10, 3, rank, world, dev, dist)
+      sec["train_configs3"] = {"workload": tr["config"]["workload"], "parallelism": tr["config"]["parallelism"],
+                               "steps": tr["steps"], "warmup": tr["warmup"], "ms_per_step": tr["ms_per_step"],
+                               "samples_per_s": tr["value"], "TFLOP_per_s": tr["algorithmic_TFLOP_per_s"],
+                               "whole_step_frac": round(tr["algorithmic_TFLOP_per_s"] / PEAK_FP16_DENSE_TFLOPS / world, 4),
+                               "loss": tr["loss"], "roofline": tr["roofline"]}
+    except Exception as e:     # a secondary config must never take the headline line down with it
+      sec["error"] = f"{type(e).__name__}: {e}"
+    sec["wall_s"] = round(time.perf_counter() - t_sec, 1)
+    out["secondary"] = sec
 
   if rank == 0:
-    samples_per_step = B * T * 256 * world
-    value = samples_per_step * args.steps / elapsed
-    n_wn = int(cnt[2])
-    avg_wn_ms = ms[2] / max(1, n_wn)
-    launches_per_step = hp.n_flows * hp.n_layers
-    flops_per_launch = 2.0 * wn_layer_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
-    achieved = flops_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
-    executed_per_launch = 2.0 * wn_layer_executed_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
-    executed = executed_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
-    out = {
-      "metric": "audio samples/sec/GPU (22.05 kHz) WaveGlow-256 infer; real-time factor",
-      "value": round(value, 1),
-      "unit": "samples/s",
-      "n_gpus": world,
-      "steps": args.steps,
-      "warmup": args.warmup,
-      "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-      "higher_is_better": True,
-      "scaling": "weak",
-      "vs_baseline": None,
-      "dtype": "f16 MFMA operands, f32 accumulate/flow state, %s I/O" % args.dtype,
-      "data": "synthetic (random 80xT log-mels, synthetic weights of the LJS-v3 256ch architecture)",
-      "config": {"workload": f"{workload_label(args)}: {args.channels}ch WaveGlow.infer, batch={B}/GPU mels 80x{T}, "
-                             f"{args.dtype} I/O, sigma=0.6",
-                 "per_gpu_samples_per_step": B * T * 256, "parallelism": f"utterance-sharded x{world}, no collective"},
-      "real_time_factor": round(value / 22050.0, 1),
-      "samples_per_s_per_gpu": round(value / world, 1),
-      "roofline": {"bound": "mfma", "kernel": "wn_layer_kernel", "achieved": round(achieved, 2),
-                   "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4),
-                   "traffic": pmc_traffic_bytes(args), "avg_launch_ms": round(avg_wn_ms, 4), "launches_timed": n_wn,
-                   "algorithmic_flops_per_launch": flops_per_launch,
-                   # what the matrix cores actually execute after the weight folds (fewer MACs for the same result)
-                   "executed_flops_per_launch": executed_per_launch, "executed_achieved": round(executed, 2),
-                   "executed_frac": round(executed / PEAK_FP16_DENSE_TFLOPS, 4),
-                   "kernel_ms_per_step": {"mel_pack": round(ms[0] / args.steps, 3), "flow_start": round(ms[1] / args.steps, 3),
-                                          "wn_layer": round(ms[2] / args.steps, 3), "memset": round(ms[3] / args.steps, 3)}},
-    }
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(hp, sd)
     print(json.dumps(out), flush=True)
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  finish()
 
 
 if __name__ == "__main__":

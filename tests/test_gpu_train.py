@@ -25,6 +25,14 @@ FWD_TOL = 2e-3
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+@pytest.fixture(autouse=True)
+def _poisoned_gradient_buffer(monkeypatch):
+  """Every test of this module starts its flat gradient buffer (waveglow_amd.train.GradBuffers, torch.empty in
+  production) from NaN: an entry the library never writes -- also a PADDED one that pack_weights' backward slices off
+  before any parity check sees it -- makes ``model.grad_finite`` (isfinite of the sum over the WHOLE buffer) false."""
+  monkeypatch.setenv("WG_TRAIN_POISON_GRADS", "1")
+
+
 def _setup(over, B, T, wseed, crop=96):
   hp = HParams(**over)
   sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=wseed))
@@ -44,6 +52,7 @@ def _gpu_step(hp, sd, mel, wav, sigma=1.0):
   loss = WaveGlowLoss(sigma)(y, None)
   loss.backward()
   torch.cuda.synchronize()
+  assert bool(model.grad_finite), "the library left an entry of the (NaN-poisoned) gradient buffer unwritten"
   grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
   return float(loss.detach()), y, grads
 
@@ -251,13 +260,15 @@ def test_gradient_allreduce_over_rccl_single_rank():
     assert torch.equal(a, p.grad)
 
 
-def test_full_size_directional_derivative_and_forward_consistency():
-  """BASELINE configs[3] shapes (256 channels, 16 000-sample segments; batch 8 to keep the test short), where no CPU
+@pytest.mark.parametrize("B", [8, 32])
+def test_full_size_directional_derivative_and_forward_consistency(B):
+  """BASELINE configs[3] shapes (256 channels, 16 000-sample segments; batch 8, and the config's real per-GPU batch of 32:
+  the launcher then picks two forward chains and 22 GB of saved planes by itself), where no CPU
   oracle finishes in seconds: size-independent checks.  (1) the training forward (saved activations, unfolded cond
   path) and the inference-style forward (folded weights, wn_layer_kernel) agree on the loss; (2) the gradient of the
   library's backward predicts the central finite difference of that loss along the gradient direction."""
-  hp, sd, mel, wav = _setup(dict(), 8, 63, 7, crop=256 * 63 - 16000)
-  assert wav.shape == (8, 16000)
+  hp, sd, mel, wav = _setup(dict(), B, 63, 7, crop=256 * 63 - 16000)
+  assert wav.shape == (B, 16000)
   model = WaveGlow(hp)
   model.load_state_dict(sd)
   model = model.to("cuda:0").train()
@@ -265,6 +276,7 @@ def test_full_size_directional_derivative_and_forward_consistency():
   mel_d, wav_d = mel.cuda(), wav.cuda()
   loss = crit(model((mel_d, wav_d)), None)
   loss.backward()
+  assert bool(model.grad_finite)
   grads = [p.grad.detach().clone() for p in model.parameters()]
   gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
   assert np.isfinite(gnorm) and gnorm > 0
@@ -324,6 +336,7 @@ def test_backward_with_fused_per_flow_allreduce_single_rank():
     torch.cuda.synchronize()
   finally:
     dist.destroy_process_group()
+  assert bool(model.grad_finite)      # poisoned buffer (module fixture): the per-flow calls together write every entry
   for name, p in model.named_parameters():
     assert torch.equal(p.grad.cpu(), ref[name]), name
 

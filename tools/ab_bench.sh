@@ -9,7 +9,7 @@ mkdir -p $ROOT/gpurun_out
 for round in 1 2 3; do
   for v in A B; do
     if [ $v = A ]; then unset WAVEGLOW_AMD_LIB; else export WAVEGLOW_AMD_LIB=$LIB; fi
-    timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | python -c "
+    timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 10 --warmup 3 "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
   if l.startswith('{'):

@@ -6,7 +6,7 @@ ROUNDS=${ROUNDS:-3}
 for round in $(seq 1 $ROUNDS); do
   for v in "" "$@"; do
     if [ -z "$v" ]; then unset WAVEGLOW_AMD_LIB; name="A (in-tree)"; else export WAVEGLOW_AMD_LIB=$ROOT/$v; name=$(basename $v .so); fi
-    timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 $BENCH_ARGS 2>/dev/null | python -c "
+    timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 10 --warmup 3 $BENCH_ARGS 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
   if l.startswith('{'):

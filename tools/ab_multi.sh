@@ -10,7 +10,7 @@ done
 for round in 1 2 3; do
   for v in $(seq 0 $i); do
     if [ $v = 0 ]; then unset WAVEGLOW_AMD_LIB; name="A (in-tree)"; else export WAVEGLOW_AMD_LIB=$ROOT/gpurun_out/lib_v$v.so; name="V$v"; fi
-    timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c "
+    timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 10 --warmup 3 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
   if l.startswith('{'):

@@ -128,6 +128,10 @@ struct wg_handle {
   hipStream_t aux[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
   size_t sync_next = 0;
+  // events of wg_train_backward's long-lived marks (recorded on one stream, waited on one or two flows later): a pool of
+  // their own, one event per role, so that no number of ring events consumed in between can re-record one under a wait
+  hipEvent_t mark_ev[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -220,6 +224,8 @@ int wg_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 // accessors for the other translation units of the library (train_api.cpp)
 const wg_config* wg_internal_config(const wg_handle* h) { return h ? &h->cfg : nullptr; }
 const int* wg_internal_flow_channels(const wg_handle* h) { return h ? h->c_k.data() : nullptr; }
+int wg_internal_device(const wg_handle* h) { return h ? h->device : -1; }
+int wg_internal_n_cu(const wg_handle* h) { return h ? h->n_cu : 256; }   // of the HANDLE's device (wg_create)
 wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T) { return make_geom(h->cfg, B, L, T); }
 // one profiling event of class cls on stream s (a no-op unless wg_profile_enable is on); events come in begin/end pairs
 void wg_internal_prof_event(wg_handle* h, void* s, int cls) {
@@ -251,8 +257,15 @@ hipStream_t wg_internal_aux_stream(wg_handle* h, int i) {
   }
   return h->aux[i];
 }
+// Event `slot` of the mark pool (no timing), created on first use.
+hipEvent_t wg_internal_mark_event(wg_handle* h, int slot) {
+  if (!h || slot < 0 || slot >= 16) return nullptr;
+  if (!h->mark_ev[slot] && hipEventCreateWithFlags(&h->mark_ev[slot], hipEventDisableTiming) != hipSuccess) h->mark_ev[slot] = nullptr;
+  return h->mark_ev[slot];
+}
 // Next event of the ordering ring (no timing).  A wait captures the record that precedes it in host order, so an event
-// may be recorded again while earlier waits on it are still pending on the device.
+// may be recorded again while earlier waits on it are still pending on the device.  Ring events are for record-then-wait
+// pairs issued back to back (order_after); anything waited on LATER uses wg_internal_mark_event.
 hipEvent_t wg_internal_sync_event(wg_handle* h) {
   constexpr size_t kRing = 1024;
   if (!h) return nullptr;
@@ -291,6 +304,10 @@ int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
   wg_handle* h = new wg_handle();
   h->cfg = c;
   h->device = device_id;
+  {
+    int ncu = 0;   // of THIS device, whatever the caller's current device is
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) h->n_cu = ncu;
+  }
   h->NS = c.n_mel_channels * c.n_group;
   h->c_k = ck;
   if (const char* e = getenv("WG_FORCE_BN")) h->force_bn = atoi(e);
@@ -323,6 +340,8 @@ int wg_destroy(wg_handle* h) {
   if (h->d_cond) hipFree(h->d_cond);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
+  for (hipEvent_t e : h->mark_ev)
+    if (e) hipEventDestroy(e);
   for (hipStream_t st : h->aux)
     if (st) hipStreamDestroy(st);
   delete h;

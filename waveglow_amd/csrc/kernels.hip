@@ -1145,7 +1145,10 @@ template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS 
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr int smem = 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
+  int cur_dev = 0;
+  if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
+  bool& attr_done = attr_done_dev[cur_dev];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -220,12 +220,14 @@ plane_gemm_kernel(const PGemmArgs a) {
 }
 
 namespace {
-int device_cus() {
-  static int n = 0;
+int device_cus() {      // of the launch's (current) device
+  static int n_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int& n = n_dev[dev];
   if (!n) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
     if (n <= 0) n = 256;
   }
   return n;
@@ -605,7 +607,10 @@ hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, const SlabSeg* r
   hipError_t e = check_wgrad(a);
   if (e == hipSuccess && b) e = check_wgrad(*b);
   if (e != hipSuccess) return e;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
+  int cur_dev = 0;
+  if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
+  bool& attr_done = attr_done_dev[cur_dev];
   if (!attr_done) {
     e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS_BYTES);
     if (e != hipSuccess) return e;

@@ -19,6 +19,8 @@ wg::RowGeom wg_internal_geom(const wg_handle* h, int B, int L, int T);    // api
 void wg_internal_prof_event(wg_handle* h, void* stream, int cls);         // api.cpp
 hipStream_t wg_internal_aux_stream(wg_handle* h, int i);                  // api.cpp
 hipEvent_t wg_internal_sync_event(wg_handle* h);                          // api.cpp
+hipEvent_t wg_internal_mark_event(wg_handle* h, int slot);                // api.cpp
+int wg_internal_n_cu(const wg_handle* h);                                 // api.cpp
 
 namespace {
 
@@ -146,12 +148,7 @@ int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* wo
     return wg_set_error(WG_ERR_INVALID, "upsampled mel shorter than audio");
   const int L = audio_len / c.n_group;
   x.g = wg_internal_geom(h, B, L, n_frames);
-  x.n_cu = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      x.n_cu = v;
-  }
+  x.n_cu = wg_internal_n_cu(h);     // of the handle's device: decides the chain geometry (workspace layout) below
   // Chains.  A WN-layer launch runs ceil(tiles / CUs) rounds and the next layer waits for its last, partly filled
   // round (config 4: 576 tiles of 128 columns on 256 CUs = 2.25 rounds, a quarter of the chip-time idle).  The two
   // halves of the batch never exchange data inside a WN, so they run as two chains of half-size launches on two
@@ -516,11 +513,14 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   // run beside the MFMA-bound ones), from the slab set the launch before wrote; the last one gets a launch of its own.
   SlabSeg pend[kMaxSlabSegs];
   int n_pend = 0, n_layer = 0;
+  // (marks are waited on one or two flows after their record: events of their own, wg_internal_mark_event, slots
+  //  0-7 = w_done[layer], 8-9 = w_flow[parity]; a null entry = not recorded in this call, nothing to wait for)
   hipEvent_t w_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, w_flow[2] = {nullptr, nullptr};
-  auto mark = [&](hipStream_t st, hipEvent_t& e) -> hipError_t {
+  static_assert(sizeof(w_done) / sizeof(w_done[0]) + sizeof(w_flow) / sizeof(w_flow[0]) <= 16, "mark pool too small");
+  auto mark = [&](hipStream_t st, hipEvent_t& e, int slot) -> hipError_t {
     e = nullptr;
     if (x.serial) return hipSuccess;
-    e = wg_internal_sync_event(h);
+    e = wg_internal_mark_event(h, slot);
     return e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
   };
   auto wait_for = [&](hipStream_t st, hipEvent_t e) -> hipError_t { return e ? hipStreamWaitEvent(st, e, 0) : hipSuccess; };
@@ -642,7 +642,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         add(w.slab2[set] + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
         // d out_init = sum over columns of (d b | d log_s), once per flow
         if (i == 0) add(w.part2[set] + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k], 0, 0);
-        TR_ORDER(mark(sW, w_done[i]));
+        TR_ORDER(mark(sW, w_done[i], i));
       }
       {
         // d x_i = d x_{i+1} + sum_tap W_in[tap]^T d pre(t - (tap-1) d)   (wn_layer_kernel MODE 2: taps at +d, 0, -d)
@@ -668,7 +668,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         gx = gxi;
       }
     }
-    TR_ORDER(mark(sW, w_flow[k & 1]));
+    TR_ORDER(mark(sW, w_flow[k & 1], 8 + (k & 1)));
     TR_ORDER(order_after(h, sB, s));
     {
       StartWgradArgs a;

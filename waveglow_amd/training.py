@@ -276,6 +276,13 @@ def train(custom_hparams: Optional[Dict[str, str]], logdir: Optional[Path], trai
       # with the fused optimiser the overflow check gates the update ON THE DEVICE (torch's found_inf hook, as
       # GradScaler uses it: the step is skipped, nothing is written), so the host reads the flag only afterwards.
       finite = getattr(model, "grad_finite", None)      # set by the library's backward (waveglow_amd/train.py)
+      if reducer is not None and finite is not None:
+        # the unfused exchange ran AFTER backward() computed the flag, so the flag is rank-local while the summed gradients
+        # are not: every rank must take the same branch below (the per-flow path computes its flag after the all-reduce)
+        bad = (~finite).to(torch.float32).reshape(1)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX, group=reducer.group)
+        finite = bad.reshape(()) == 0
+        model.grad_finite = finite
       gated = finite is not None and any(g.get("fused") for g in optimizer.param_groups)
       if gated:
         optimizer.found_inf = (~finite).to(torch.float32).reshape(())
