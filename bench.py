@@ -281,19 +281,24 @@ def build_infer_model(channels, dev):
   return hp, sd, model.to(dev).eval()
 
 
-def run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist):
+def run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist, profile=True):
   """`steps` timed WaveGlow.infer calls (noise draws included) on one batch resident in HBM; returns
-  (elapsed seconds: max over ranks, per-class kernel ms, launch counts)."""
+  (elapsed seconds: max over ranks, per-class kernel ms, launch counts).  `profile`: hipEvents around every launch
+  inside the timed region (the headline: two event records per 0.5 ms launch are noise there); False: the events are
+  taken in a pass of their own after the timed one (single-utterance latency: 110 launches of ~25 us per call)."""
   from waveglow_amd import synthetic
   dtype = torch.float16 if dtype_name == "fp16" else torch.float32
   mel = synthetic.make_mel(B, T, seed=1234 + rank).to(dev, dtype)
   sigma = 0.6
   torch.manual_seed(4321 + rank)
+  ms = (C.c_double * 4)()
+  cnt = (C.c_int64 * 4)()
   with torch.no_grad():
     for _ in range(warmup):
       audio = model.infer(mel, sigma=sigma)
     eng = model._engine
-    eng.lib.wg_profile_enable(eng.handle, 1)
+    if profile:
+      eng.lib.wg_profile_enable(eng.handle, 1)
     torch.cuda.synchronize(dev)
     if dist is not None:
       dist.barrier()
@@ -304,9 +309,12 @@ def run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist):
     if dist is not None:
       dist.barrier()
     elapsed = time.perf_counter() - t0
+    if not profile:
+      eng.lib.wg_profile_enable(eng.handle, 1)
+      for _ in range(steps):
+        audio = model.infer(mel, sigma=sigma)
+      torch.cuda.synchronize(dev)
   assert torch.isfinite(audio).all()
-  ms = (C.c_double * 4)()
-  cnt = (C.c_int64 * 4)()
   eng.lib.wg_profile_read(eng.handle, ms, cnt, 4)
   eng.lib.wg_profile_enable(eng.handle, 0)
   if dist is not None:
@@ -337,7 +345,7 @@ def infer_roofline(hp, B, T, steps, ms, cnt, traffic=None):
 
 def secondary_infer(label, hp, model, B, T, dtype_name, steps, warmup, rank, world, dev, dist):
   """One more BASELINE config, after the headline's timed region: the same measurement, condensed."""
-  elapsed, ms, cnt = run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist)
+  elapsed, ms, cnt = run_infer(hp, model, B, T, dtype_name, steps, warmup, rank, dev, dist, profile=False)
   roof = infer_roofline(hp, B, T, steps, ms, cnt)
   samples = B * T * 256 * world
   flops_per_sample = 2.0 * (81235408 if hp.n_channels == 256 else 261355984) / 8 if hp.n_channels in (256, 512) else None

@@ -125,7 +125,7 @@ struct wg_handle {
   int64_t prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // library-owned streams of the training direction (independent chains of one call run side by side, joined back into
   // the caller's stream before the call returns) and a ring of ordering events for them
-  hipStream_t aux[2] = {nullptr, nullptr};
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
   size_t sync_next = 0;
   // events of wg_train_backward's long-lived marks (recorded on one stream, waited on one or two flows later): a pool of
@@ -240,15 +240,15 @@ void wg_internal_prof_event(wg_handle* h, void* s, int cls) {
   hipEventRecord(h->ev[h->ev_used++], (hipStream_t)s);
 }
 
-// Library-owned stream i (0: second chain, normal priority; 1: work with slack, lowest priority) of the handle's device.
+// Library-owned stream i (0: second chain, normal priority; 1, 2: work with slack, lowest priority) of the handle's device.
 hipStream_t wg_internal_aux_stream(wg_handle* h, int i) {
-  if (!h || i < 0 || i > 1) return nullptr;
+  if (!h || i < 0 || i > 2) return nullptr;
   if (!h->aux[i]) {
     int lo = 0, hi = 0, prev = -1;
     hipStream_t st = nullptr;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != h->device) (void)hipSetDevice(h->device);
-    if (i == 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+    if (i >= 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
       if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
     }
     if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;

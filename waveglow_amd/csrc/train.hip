@@ -284,9 +284,9 @@ hipError_t launch_plane_gemm(const PGemmArgs& a, hipStream_t s) {
 // Slab reduction.  out[i] = scale * sum_s slabs[s][i]   (fixed order: bitwise reproducible).  HBM-bound: 16-byte loads;
 // a workgroup is 64 float4 columns x 8 slab groups (thread (x, y) sums slabs y, y+8, ... with two independent partial
 // sums), then the eight groups are combined through LDS in a fixed order.  Up to kMaxSlabSegs independent segments per
-// launch; a segment's sums can be written in natural channel order (SlabSeg).  The body runs either as a kernel of its
-// own or as the third job of a weight-gradient launch (wgrad_kernel), where its memory-bound workgroups fill slots
-// next to MFMA-bound ones.
+// launch; a segment's sums can be written in natural channel order, and a segment can be wgrad_kernel's BLOCKED tiles
+// (SlabSeg): thread x of a workgroup then stands for lane x of the storing wave, so the reads are the stores' contiguous
+// KiB and the (row, 4 columns) of a float4 is decoded from its position (wgrad_tile, wg_train.h).
 // =============================================================================================
 struct SlabMultiArgs {
   SlabSeg seg[kMaxSlabSegs];
@@ -304,38 +304,55 @@ __device__ __forceinline__ void slab_reduce_body(const SlabMultiArgs& a, unsigne
   const unsigned nb = a.first_block[si + 1] - a.first_block[si];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const size_t n4 = g.n >> 2;
-  for (size_t base = (size_t)(block - a.first_block[si]) * 64; base < n4; base += (size_t)nb * 64) {
-    const size_t i = base + tx;
+  const int groups = g.blocked ? g.n_groups : 1, per_group = g.n_slabs / groups;
+  const size_t items = n4 * (size_t)groups;        // (group, float4) pairs; n4 is a multiple of 64 when groups > 1
+  for (size_t base = (size_t)(block - a.first_block[si]) * 64; base < items; base += (size_t)nb * 64) {
+    const size_t it = base + tx;
+    const size_t grp = it / n4, i = it - grp * n4;
+    const float* sl = g.slabs + grp * (size_t)per_group * g.stride;
+    bool live = it < items;
+    size_t e = 4 * i;                              // output element of this float4
+    if (live && g.blocked) {
+      const unsigned lane = (unsigned)i & 63u, q = ((unsigned)i >> 6) & 31u, wv = ((unsigned)i >> 11) & 7u;
+      const WgradTile t = wgrad_tile(g.m_chunks, g.k_chunks, (int)(i >> 14));
+      const int wm = t.shape ? (int)(wv >> 1) : (int)(wv >> 2), wk = t.shape ? (int)(wv & 1) : (int)(wv & 3);
+      const int mch = t.mc0 + 2 * wm + (int)(q >> 4), kch = t.kc0 + wk;
+      live = mch < g.m_chunks && kch < g.k_chunks;          // sub-tiles past the matrix are never stored
+      size_t m = (size_t)mch * 64 + 16 * ((q >> 2) & 3u) + (lane & 15u);
+      size_t k = (size_t)kch * 64 + 16 * (q & 3u) + 4 * (lane >> 4);
+      if (g.perm & 1) m = pos_to_natural(m);
+      if (g.perm & 2) k = pos_to_natural(k);
+      e = m * (size_t)g.row_len + k;
+    }
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    if (i < n4) {
+    if (live) {
       int k = ty;
-      for (; k + SR_GROUPS < g.n_slabs; k += 2 * SR_GROUPS) {
-        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
-        const float4 v = *(const float4*)(g.slabs + (size_t)(k + SR_GROUPS) * g.stride + 4 * i);
+      for (; k + SR_GROUPS < per_group; k += 2 * SR_GROUPS) {
+        const float4 u = *(const float4*)(sl + (size_t)k * g.stride + 4 * i);
+        const float4 v = *(const float4*)(sl + (size_t)(k + SR_GROUPS) * g.stride + 4 * i);
         a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
         a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
       }
-      if (k < g.n_slabs) {
-        const float4 u = *(const float4*)(g.slabs + (size_t)k * g.stride + 4 * i);
+      if (k < per_group) {
+        const float4 u = *(const float4*)(sl + (size_t)k * g.stride + 4 * i);
         a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
       }
     }
     part[ty][tx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
     __syncthreads();
-    if (ty == 0 && i < n4) {
+    if (ty == 0 && live) {
       float4 o;
 #define WG_SR_COMBINE(c) (((part[0][tx].c + part[1][tx].c) + (part[2][tx].c + part[3][tx].c)) + \
                           ((part[4][tx].c + part[5][tx].c) + (part[6][tx].c + part[7][tx].c))) * g.scale
       o.x = WG_SR_COMBINE(x); o.y = WG_SR_COMBINE(y); o.z = WG_SR_COMBINE(z); o.w = WG_SR_COMBINE(w);
 #undef WG_SR_COMBINE
-      size_t e = 4 * i;
-      if (g.perm) {
+      if (!g.blocked && g.perm) {
         size_t m = e / (size_t)g.row_len, k = e - m * (size_t)g.row_len;
         if (g.perm & 1) m = pos_to_natural(m);
         if (g.perm & 2) k = pos_to_natural(k);
         e = m * (size_t)g.row_len + k;
       }
-      *(float4*)(g.out + e) = o;
+      *(float4*)(g.out + grp * g.out_group_stride + e) = o;
     }
     __syncthreads();
   }
@@ -353,14 +370,22 @@ unsigned plan_slab_reduce(const SlabSeg* segs, int n_segs, SlabMultiArgs& a) {
   a.n_segs = n_segs;
   unsigned total = 0;
   for (int i = 0; i < n_segs; ++i) {
-    if ((segs[i].n & 3) || (segs[i].stride & 3) || !segs[i].slabs || !segs[i].out) return 0;
-    if (segs[i].perm && (segs[i].row_len < 4 || (segs[i].row_len & 3) || segs[i].n % (size_t)segs[i].row_len)) return 0;
-    if ((segs[i].perm & 2) && (segs[i].row_len & 31)) return 0;
-    if ((segs[i].perm & 1) && ((segs[i].n / (size_t)segs[i].row_len) & 31)) return 0;
-    a.seg[i] = segs[i];
+    const SlabSeg& g = segs[i];
+    if ((g.n & 3) || (g.stride & 3) || !g.slabs || !g.out || g.n_slabs < 1) return 0;
+    if (g.blocked) {
+      if (g.m_chunks < 1 || g.k_chunks < 1 || g.n_groups < 1 || g.n_slabs % g.n_groups || g.row_len != g.k_chunks * 64 ||
+          g.n != (size_t)wgrad_tiles(g.m_chunks, g.k_chunks) * kWgradTileFloats)
+        return 0;
+    } else {
+      if (g.perm && (g.row_len < 4 || (g.row_len & 3) || g.n % (size_t)g.row_len)) return 0;
+      if ((g.perm & 2) && (g.row_len & 31)) return 0;
+      if ((g.perm & 1) && ((g.n / (size_t)g.row_len) & 31)) return 0;
+    }
+    a.seg[i] = g;
+    if (!g.blocked) { a.seg[i].n_groups = 1; a.seg[i].out_group_stride = 0; }
     a.first_block[i] = total;
-    size_t blocks = (segs[i].n / 4 + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
+    size_t blocks = (g.n / 4 * (size_t)(g.blocked ? g.n_groups : 1) + 63) / 64;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     total += (unsigned)blocks;
   }
@@ -378,36 +403,44 @@ hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t
 }
 
 // =============================================================================================
-// Weight gradient.  out[slab][m][k'] = sum_rows G[row][m] X[row + shift][k'] over the rows of one slab (a phase, or
-// 1/row_split of a phase).  Workgroup = 8 waves = a 256 (m) x 128 (k') output tile; wave (wm, wk) owns a 64 x 64
-// quadrant as 4 x 4 MFMA tiles of 16 x 16.  Both operands are [row][channel] planes and the contraction runs over
-// ROWS, so an MFMA fragment (8 k = rows, one channel per lane) is a column of the LDS tile: fetched with
-// ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4-row x 16-column block
-// (cdna_hip_programming.md T10).  Chunks past the end of an operand are clamped to its last chunk: their products are
-// computed and never stored.  Guard / invalid rows of G are zero by construction (every producer writes zeros there),
-// so no row masking.
+// Weight gradient.  dW[m][k'] = sum_rows G[row][m] X[row + shift][k'].  Both operands are [row][channel] planes and the
+// contraction runs over ROWS, so an MFMA fragment (8 k = rows, one channel per lane) is a column of the LDS tile:
+// fetched with ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4-row x 16-column block
+// (cdna_hip_programming.md T10).  Guard / invalid rows of G are zero by construction (every producer writes zeros
+// there), so no row masking.  v_mfma_f32_16x16x32_f16: one MFMA spans the 32 rows of a step (against 32x32x16 tiles the
+// chip holds a higher clock with this shape: MI355X_MICROARCH.md, DVFS item 7).
 //
-// v_mfma_f32_16x16x32_f16: one MFMA spans the 32 rows of a step (same-box A/B against a 32x32x16 version: 10 % faster
-// at equal MFMA cycles -- the chip holds a higher clock with the 16x16 shape).  Lane group g reads rows 4g..4g+3 and
-// 16+4g..16+4g+3, so a 32-lane half touches 8 consecutive rows x 32 B.
-//
-// Staging: LDS-DMA (global_load_lds_dwordx4) into a three-stage ring, two steps ahead (round 1 staged the tiles
-// global -> VGPR -> ds_write: 24 more registers, a commit phase before every barrier, one workgroup per CU; this form
-// fits 128 registers = two workgroups per CU).  A DMA instruction writes 64 consecutive 16-byte slots, so the LDS
-// tile cannot be padded; it is [unit = chunk x 8-row block][8 rows][128 B] with the 32-byte column blocks of row r
-// XOR-ed with (r >> 1) & 3 (applied on the SOURCE side: lane -> which 16 bytes of its row it fetches): the 8 rows x
-// 32 B a 32-lane half of ds_read_b64_tr_b16 touches then fall on 8 different 32-byte bank groups.  Per step and
-// thread 3 DMAs (units w, 8 + w of G; unit w of X), all hand-counted (vmcnt): see glds16 in kernels.hip.
-//
-// One launch carries up to TWO jobs (WgradPair): a layer's d W1 (704 workgroups of 72 steps at config 4: 1.4 rounds of
-// the 512 resident workgroups) and its d W2 / end x skip (512 workgroups of 18 steps), whose workgroups fill the
-// slots the first job's last round leaves idle.  Within a job, the workgroups of one slab (they share its G and X
-// rows) are consecutive on one XCD (xcd_order): a step's rows come out of HBM once per slab, not once per XCD.
+// Round 3: ONE workgroup per CU with a 256 x 256 output tile (half of the CU's register file is accumulators).  The
+// round-2 kernel (256 x 128 tiles, two workgroups per CU, one slab per phase) streamed 24 KiB of operands from L2 per
+// 2.1 MFLOP: 1.7 GB of L2 requests per 155 us launch and 38 % MFMA-busy -- the operand stream, not the matrix pipe, set
+// its pace, and its 704 + 256 workgroups ran in 1.9 rounds.  Now:
+//   * tile = 4 G chunks x 4 X chunks (8 waves as 2 x 4, each 128 x 64 = 8 x 4 MFMA tiles) or, over the last 1-3 X chunks
+//     of a matrix whose K' is not a multiple of 256, 8 G chunks x 2 X chunks (waves 4 x 2): the same wave shape, so
+//     d W1 [512 x 1408] is 10 + 1 tiles with no padding work.  32 KiB per 4.2 MFLOP (40 for the 8 x 2 shape);
+//   * the rows (32 phases x Rp) are cut into n_slabs contiguous ranges of 32-row steps -- a range may start and end
+//     anywhere, also inside a phase -- with n_slabs = CUs / tiles (wg_train_backward): (tiles x slabs) workgroups are
+//     ONE round of the chip, every workgroup equally long, and the slabs to write and reduce are 21 instead of 32;
+//   * both jobs of a layer ride in one launch over the same slab partition; d (W_end W_skip) = d out x acts^T needs only
+//     16 rows of a fifth G plane: the d W2 tile stages that plane as one more slice and its first wave row spends 4 of
+//     its 36 MFMAs per step on it (`extra`) instead of a 256-row tile that would be 94 % padding;
+//   * bias gradients (column sums of G) ride on the matrix pipe: one MFMA per fragment against a 0/1 selector that
+//     drops the sum into row i of ONE 16 x 16 accumulator (4 registers for all of a wave's fragments);
+//   * operands swapped (A = X fragment, B = G fragment): a lane's four results are four consecutive K' of one row, and
+//     the tile is stored in accumulator order, one contiguous KiB per store instruction (the round-2 epilogue wrote
+//     64-byte segments: 2 ms per step); slab_reduce un-blocks.
+// Staging: LDS-DMA (global_load_lds_dwordx4) into a three-stage ring, two steps ahead, hand-counted vmcnt.  A DMA
+// instruction writes 64 consecutive 16-byte slots, so the LDS tile cannot be padded; a slice is [32 rows][128 B] of one
+// chunk with the 32-byte column blocks of row r XOR-ed with (r >> 1) & 3 (applied on the SOURCE side: lane -> which 16
+// bytes of its row it fetches): the 8 rows x 32 B a 32-lane half of ds_read_b64_tr_b16 touches then fall on 8 different
+// 32-byte bank groups.  Wave w stages the 8-row block w & 3 of slices (w >> 2), (w >> 2) + 2, ...
+// Workgroups of one slab (they share its G and X rows) are consecutive on one XCD (xcd_order).
 // =============================================================================================
-constexpr int WG_STEP = 32;     // rows per step (64-row steps -- 16 MFMAs between barriers -- measured 10 % slower)
+constexpr int WG_STEP = 32;     // rows per step
 constexpr int WD_STAGES = 3;
-constexpr int WD_STAGE_BYTES = 24 * 1024;                 // 16 units of G (4 chunks x 32 rows x 128 B) + 8 of X
-constexpr int WD_LDS_BYTES = WD_STAGES * WD_STAGE_BYTES;  // 72 KB: two workgroups per CU
+constexpr int WD_MAX_SLICES = 11;                          // 8 + 2 + extra
+constexpr int WD_STAGE_BYTES = WD_MAX_SLICES * 4096;       // 44 KiB
+constexpr int WD_LDS_BYTES = WD_STAGES * WD_STAGE_BYTES;   // 132 KiB: one workgroup per CU
+constexpr int WD_MAX_DMA = (WD_MAX_SLICES + 1) / 2;        // slices per wave
 
 namespace {
 __device__ __forceinline__ void tr_glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
@@ -419,95 +452,125 @@ template <int N> __device__ __forceinline__ void tr_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+// all but the `keep` youngest vector-memory operations of this wave have landed (keep is wave-uniform)
+__device__ __forceinline__ void tr_wait_keep(int keep) {
+  switch (keep) {
+    case 0: tr_wait_vm<0>(); break;
+    case 1: tr_wait_vm<1>(); break;
+    case 2: tr_wait_vm<2>(); break;
+    case 3: tr_wait_vm<3>(); break;
+    case 4: tr_wait_vm<4>(); break;
+    case 5: tr_wait_vm<5>(); break;
+    default: tr_wait_vm<6>(); break;
+  }
+}
 __device__ __forceinline__ const char* uniform_ptr(const void* p) {
   const unsigned long long v = (unsigned long long)p;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (const char*)(((unsigned long long)hi << 32) | lo);
 }
-struct WgradPair {
-  WgradArgs job[2];
-  unsigned nwg[2];        // workgroups of each job (the second may be 0)
-  SlabMultiArgs red;      // optional third job: a slab reduction (of the PREVIOUS layer's slabs), red.n_segs = 0: none
+struct WgradLaunch {
+  WgradJob job[2];
+  int tiles[2];           // tiles of each job (the second may be 0)
+  RowGeom g;
+  int n_slabs;
 };
-inline unsigned wgrad_workgroups(const WgradArgs& a) {
-  return (unsigned)((a.m_chunks + 3) / 4) * (unsigned)((a.k_chunks + 1) / 2) * (unsigned)(kPhases * a.row_split / a.phases_per_slab);
-}
 }  // namespace
 
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) wgrad_kernel(const WgradPair pr) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad_kernel(const WgradLaunch L) {
   extern __shared__ __attribute__((aligned(1024))) _Float16 wg_smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wk = w & 1;
-  if (blockIdx.x >= pr.nwg[0] + pr.nwg[1]) {        // third job: memory-bound, dispatched last, fills the tail
-    slab_reduce_body(pr.red, blockIdx.x - pr.nwg[0] - pr.nwg[1], (float4 (*)[64])wg_smem);
-    return;
-  }
-  const bool second = blockIdx.x >= pr.nwg[0];
-  const WgradArgs& a = second ? pr.job[1] : pr.job[0];
-  const RowGeom& g = a.g;
-  const unsigned gx = (unsigned)(a.m_chunks + 3) / 4, gy = (unsigned)(a.k_chunks + 1) / 2;
-  const unsigned wgid = xcd_order(second ? blockIdx.x - pr.nwg[0] : blockIdx.x, second ? pr.nwg[1] : pr.nwg[0]);
-  const int bx = (int)(wgid % gx), by = (int)((wgid / gx) % gy);
-  const int slab = (int)(wgid / (gx * gy));
-  const int pps = a.phases_per_slab;
-  const int p0 = pps > 1 ? slab * pps : slab / a.row_split, rs = pps > 1 ? 0 : slab - p0 * a.row_split;
-  const int rows_per = g.Rp / a.row_split;
-  const int mc0 = bx * 4, kc0 = by * 2;
+  const RowGeom& g = L.g;
+  const int T = L.tiles[0] + L.tiles[1];
+  const unsigned wgid = xcd_order(blockIdx.x, gridDim.x);
+  const int slab = (int)(wgid / (unsigned)T), tt = (int)(wgid - (unsigned)slab * (unsigned)T);
+  const bool second = tt >= L.tiles[0];
+  const WgradJob& a = second ? L.job[1] : L.job[0];
+  const int tile = second ? tt - L.tiles[0] : tt;
+  const WgradTile tl = wgrad_tile(a.m_chunks, a.k_chunks, tile);
+  const int MC = tl.shape ? 8 : 4, KCW = tl.shape ? 2 : 4;
+  const int wm = tl.shape ? (w >> 1) : (w >> 2), wk = tl.shape ? (w & 1) : (w & 3);
+  const bool do_extra = tl.extra_duty && a.G_extra != nullptr;
+  const bool do_bias = tl.bias_duty && a.bias_out != nullptr;
   const size_t R64 = (size_t)g.R * 64;
 
-  // DMA units of this wave: G chunk (w >> 2) and 2 + (w >> 2), X chunk (w >> 2); 8-row block rb = w & 3 of the step
+  // ---- staging duty of this wave: 8-row block rb of slices (w >> 2) + 2 j.  Slices past the matrix are not staged:
+  // the fragments read from them are garbage, and so are the accumulators they feed, which are never stored.
   const int rb = w & 3;
-  auto g_chunk_base = [&](int e) -> const _Float16* {
-    const int gch = (mc0 + e < a.m_chunks) ? mc0 + e : a.m_chunks - 1;
-    return (a.G_last && gch == a.m_chunks - 1) ? a.G_last : a.G + (size_t)gch * R64;
-  };
-  const _Float16* const gb0 = g_chunk_base(w >> 2);
-  const _Float16* const gb1 = g_chunk_base(2 + (w >> 2));
-  const _Float16* xb;
-  int xdt;
-  {
-    int c = (kc0 + (w >> 2) < a.k_chunks) ? kc0 + (w >> 2) : a.k_chunks - 1;
-    int i = 0;
-    while (c >= a.run[i].n_chunks) { c -= a.run[i].n_chunks; ++i; }
-    xb = a.run[i].base + (size_t)c * R64;
-    xdt = a.run[i].dt;
+  const _Float16* sbase[WD_MAX_DMA];
+  int sdt[WD_MAX_DMA];
+  bool son[WD_MAX_DMA];
+  int nsw = 0;
+#pragma unroll
+  for (int j = 0; j < WD_MAX_DMA; ++j) {
+    const int sl = (w >> 2) + 2 * j;
+    sbase[j] = a.G;
+    sdt[j] = 0;
+    son[j] = false;
+    if (sl < MC) {
+      son[j] = tl.mc0 + sl < a.m_chunks;
+      sbase[j] = a.G + (size_t)(son[j] ? tl.mc0 + sl : 0) * R64;
+    } else if (sl < MC + KCW) {
+      int c = tl.kc0 + (sl - MC);
+      son[j] = c < a.k_chunks;
+      if (son[j]) {
+        int i = 0;
+        while (c >= a.run[i].n_chunks) { c -= a.run[i].n_chunks; ++i; }
+        sbase[j] = a.run[i].base + (size_t)c * R64;
+        sdt[j] = a.run[i].dt;
+      }
+    } else if (sl == MC + KCW) {
+      son[j] = do_extra;
+      if (do_extra) sbase[j] = a.G_extra;
+    }
+    nsw += son[j] ? 1 : 0;
   }
-  const char *src0, *src1, *src2;
-  auto set_phase = [&](int p) {
-    const size_t grow0 = (size_t)kRowPad + (size_t)p * g.Rp + (size_t)rs * rows_per + 8 * rb;
-    src0 = uniform_ptr(gb0 + grow0 * 64);
-    src1 = uniform_ptr(gb1 + grow0 * 64);
-    src2 = uniform_ptr(xb + (shifted_row(g, p, xdt) + (size_t)rs * rows_per + 8 * rb) * 64);
-  };
   // lane -> (row lr of the 8-row block, 16-byte slot): fetches piece slot ^ (key << 1) of its row, key = (row >> 1) & 3
   const int lr = lane >> 3;
   const unsigned voff = (unsigned)(lr * 128 + (((lane & 7) ^ (((lr >> 1) & 3) << 1)) << 4));
   const unsigned smem_addr = (unsigned)(size_t)((__attribute__((address_space(3))) void*)wg_smem);
-  const unsigned lds_u = __builtin_amdgcn_readfirstlane(smem_addr + (unsigned)w * 1024u);   // unit w of stage 0
+  const unsigned lds_u = __builtin_amdgcn_readfirstlane(smem_addr + (unsigned)(w >> 2) * 4096u + (unsigned)rb * 1024u);
 
-  auto issue = [&](int st) {    // the three DMAs of step st
-    const unsigned base = lds_u + (unsigned)(st % WD_STAGES) * WD_STAGE_BYTES;
-    const size_t ro = (size_t)st * WG_STEP * 128;
-    tr_glds16(src0 + ro, voff, base);
-    tr_glds16(src1 + ro, voff, base + 8 * 1024);
-    tr_glds16(src2 + ro, voff, base + 16 * 1024);
+  // ---- this slab's range of steps (global step = phase * steps_per_phase + step)
+  const int spp = g.Rp / WG_STEP;
+  const long long total = (long long)kPhases * spp;
+  const int gs0 = (int)((long long)slab * total / L.n_slabs), gs1 = (int)((long long)(slab + 1) * total / L.n_slabs);
+  const int n_steps = gs1 - gs0;
+
+  const char* src[WD_MAX_DMA];
+  auto set_phase = [&](int p) {
+#pragma unroll
+    for (int j = 0; j < WD_MAX_DMA; ++j)
+      src[j] = uniform_ptr(sbase[j] + (shifted_row(g, p, sdt[j]) + (size_t)(8 * rb)) * 64);
+  };
+  int ip = gs0 / spp, ist = gs0 - ip * spp;     // cursor of the next step to stage
+  set_phase(ip);
+  auto issue = [&](int n) {                      // stage step n of this workgroup (the cursor's step)
+    const unsigned base = lds_u + (unsigned)(n % WD_STAGES) * WD_STAGE_BYTES;
+    const size_t ro = (size_t)ist * (WG_STEP * 128);
+#pragma unroll
+    for (int j = 0; j < WD_MAX_DMA; ++j)
+      if (son[j]) tr_glds16(src[j] + ro, voff, base + (unsigned)j * 8192u);
+    if (++ist == spp) {
+      ist = 0;
+      ++ip;
+      if (ip < kPhases) set_phase(ip);
+    }
   };
 
   typedef float f32x4v __attribute__((ext_vector_type(4)));
-  f32x4v acc[4][4], accb[4];
+  f32x4v acc[8][4], acce[4], accb;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int j = 0; j < 4; ++j) accb[j] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acce[k][j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][k][j] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) accb[i][j] = 0.0f;
   }
-  const bool do_bias = a.bias_out != nullptr && by == 0 && wk == 0;
-  half8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
 
   // transposing fragment reads: operand lane (u = lane & 15, g16 = lane >> 4) needs 8 k values of channel u of a
   // 16-channel block; k = 8 g16 + j is tile row 4 g16 + j (j < 4) / 16 + 4 g16 + j - 4 (j >= 4) -- both operands use the
@@ -516,118 +579,123 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   const int g16 = lane >> 4, u = lane & 15;
   const int tr_row = 4 * g16 + (u >> 2);
   const int tr_key = (tr_row >> 1) & 3;
-  int tr_off[4];   // halves, inside a [32 rows][64] chunk tile
+  int tr_off[4];   // halves, inside a [32 rows][64] slice
 #pragma unroll
   for (int i = 0; i < 4; ++i) tr_off[i] = tr_row * 64 + ((i ^ tr_key) << 4) + 4 * (u & 3);
-  auto frag = [&](const _Float16* chunk_tile, int i) -> half8 {
-    const _Float16* q0 = chunk_tile + tr_off[i];
+  auto frag = [&](const _Float16* slice, int i) -> half8 {
+    const _Float16* q0 = slice + tr_off[i];
     const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)q0);
     const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 16 * 64));
     const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
     return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
   };
+  // selector for the column sums: A operand whose row r (= lane & 15) is all ones, everything else zero
+  auto selector = [&](int r) -> half8 {
+    const _Float16 v = (u == r) ? (_Float16)1.0f : (_Float16)0.0f;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v;
+    return o;
+  };
 
-  const int n_steps = rows_per / WG_STEP;
-  for (int ph = 0; ph < pps; ++ph) {
-  if (ph) __syncthreads();          // the last step's stage has been read by every wave before it is refilled
-  set_phase(p0 + ph);
-  issue(0);
+  if (n_steps > 0) issue(0);
   if (n_steps > 1) issue(1);
   for (int st = 0; st < n_steps; ++st) {
-    if (st + 1 < n_steps) tr_wait_vm<3>(); else tr_wait_vm<0>();      // this thread's pieces of step st have landed
+    tr_wait_keep(st + 1 < n_steps ? nsw : 0);                           // this wave's pieces of step st have landed
     __syncthreads();                                                  // everyone's have; stage (st + 2) % 3 is free
     if (st + 2 < n_steps) issue(st + 2);
     __builtin_amdgcn_sched_barrier(0);
     const _Float16* stage = wg_smem + (size_t)(st % WD_STAGES) * (WD_STAGE_BYTES / 2);
-    const _Float16* gt = stage + wm * 2048;               // G chunk wm: 4 units of 512 halves
-    const _Float16* xt = stage + (4 + wk) * 2048;         // X chunk wk
-    // X fragments one MFMA group ahead (4 + 2 fragments live instead of 8: the kernel has to fit 128 registers for
-    // two workgroups per CU, whose waves cover each other's LDS latency)
-    half8 af[4], bf[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = frag(gt, i);
+    const _Float16* gt = stage + (2 * wm) * 2048;             // this wave's two G slices
+    const _Float16* xt = stage + (MC + wk) * 2048;            // ... and its X slice
+    half8 af[8], bf[2], ef;
     bf[0] = frag(xt, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = frag(gt + (i >> 2) * 2048, i & 3);
+    if (do_extra && wm == 0) ef = frag(stage + (MC + KCW) * 2048, 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < 3) bf[(k + 1) & 1] = frag(xt, k + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[k & 1], acc[i][k], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k & 1], af[i], acc[i][k], 0, 0, 0);
+      if (do_extra && wm == 0) acce[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k & 1], ef, acce[k], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (do_bias) {
+    if (do_bias) {      // fragments i = wk (mod KCW) of this wave's row are summed by this wave: one MFMA each
 #pragma unroll
-      for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i)
+        if ((i & (KCW - 1)) == wk && tl.mc0 + 2 * wm + (i >> 2) < a.m_chunks)     // (an unstaged slice may hold NaN: 0 x NaN)
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(i), af[i], accb, 0, 0, 0);
     }
+    if (do_extra && wm == 0 && wk == 0 && a.extra_bias_out) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(8), ef, accb, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  }
 
-  // D: col = lane & 15, row = 4 * (lane >> 4) + reg
+  // ---- epilogue.  D: row = 4 * (lane >> 4) + reg = K' inside a 16-block, col = lane & 15 = m inside a 16-block
   const int Mtot = a.m_chunks * 64, Ktot = a.k_chunks * 64;
-  if (do_bias && u == 0) {
+  const int kch = tl.kc0 + wk;
+  float4* dst = (float4*)(a.slabs + ((size_t)slab * (second ? L.tiles[1] : L.tiles[0]) + tile) * kWgradTileFloats) + (size_t)w * 32 * 64 + lane;
+  if (kch < a.k_chunks) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m0 = (mc0 + wm) * 64 + 16 * i + 4 * g16;
-      if (m0 >= Mtot) continue;
+    for (int i = 0; i < 8; ++i) {
+      if (tl.mc0 + 2 * wm + (i >> 2) >= a.m_chunks) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a.bias_out[(size_t)slab * Mtot + m0 + j] = accb[i][j];
+      for (int k = 0; k < 4; ++k) dst[(i * 4 + k) * 64] = make_float4(acc[i][k][0], acc[i][k][1], acc[i][k][2], acc[i][k][3]);
+    }
+    if (do_extra && wm == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *(float4*)(a.extra_out + ((size_t)slab * 16 + u) * Ktot + (size_t)kch * 64 + 16 * k + 4 * g16) =
+            make_float4(acce[k][0], acce[k][1], acce[k][2], acce[k][3]);
     }
   }
+  if (do_bias) {       // the sum of fragment i sits in accumulator row i: lane group i >> 2, register i & 3
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m0 = (mc0 + wm) * 64 + 16 * i + 4 * g16;
-    if (m0 >= Mtot) continue;
-    const int mrow = a.natural_rows ? (int)pos_to_natural((size_t)m0) : m0;     // aligned runs of four stay together
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int kk = (kc0 + wk) * 64 + 16 * k + u;
-      if (kk >= Ktot) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        a.out[((size_t)slab * Mtot + mrow + j) * Ktot + kk] = acc[i][k][j] * a.out_scale;
+    for (int i = 0; i < 8; ++i) {
+      const int mch = tl.mc0 + 2 * wm + (i >> 2);
+      if ((i & (KCW - 1)) == wk && mch < a.m_chunks && g16 == (i >> 2))
+        a.bias_out[(size_t)slab * Mtot + mch * 64 + 16 * (i & 3) + u] = accb[i & 3];
     }
   }
+  if (do_extra && wm == 0 && wk == 0 && a.extra_bias_out && g16 == 2) a.extra_bias_out[(size_t)slab * 16 + u] = accb[0];
 }
 
 namespace {
-hipError_t check_wgrad(const WgradArgs& a) {
-  if (a.n_runs < 1 || a.n_runs > kMaxRuns || a.row_split < 1 || a.g.Rp % (a.row_split * WG_STEP)) return hipErrorInvalidValue;
-  if (a.phases_per_slab < 1 || kPhases % a.phases_per_slab || (a.phases_per_slab > 1 && a.row_split != 1)) return hipErrorInvalidValue;
+hipError_t check_wgrad(const WgradJob& a) {
+  if (a.n_runs < 1 || a.n_runs > kMaxRuns || a.m_chunks < 1 || !a.G || !a.slabs) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.n_runs; ++i) k += a.run[i].n_chunks;
-  if (k != a.k_chunks || a.m_chunks < 1) return hipErrorInvalidValue;
+  if (k != a.k_chunks || k < 1) return hipErrorInvalidValue;
+  if (a.G_extra && !a.extra_out) return hipErrorInvalidValue;
   return hipSuccess;
 }
 }  // namespace
 
-// `b` (optional) rides in the same launch, behind `a`: put the job with the longer workgroups first; `red` (optional,
-// n_red segments) is a slab reduction that rides behind both -- of slabs that an EARLIER launch on the stream wrote
-hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, const SlabSeg* red, int n_red, hipStream_t s) {
-  hipError_t e = check_wgrad(a);
-  if (e == hipSuccess && b) e = check_wgrad(*b);
-  if (e != hipSuccess) return e;
+hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int n_slabs, hipStream_t s) {
+  if (n_jobs < 1 || n_jobs > 2 || g.Rp % WG_STEP || n_slabs < 1 || (long long)n_slabs > (long long)kPhases * (g.Rp / WG_STEP))
+    return hipErrorInvalidValue;
+  WgradLaunch L;
+  for (int j = 0; j < 2; ++j) {
+    L.job[j] = jobs[j < n_jobs ? j : 0];
+    L.tiles[j] = 0;
+    if (j < n_jobs) {
+      const hipError_t e = check_wgrad(jobs[j]);
+      if (e != hipSuccess) return e;
+      L.tiles[j] = wgrad_tiles(jobs[j].m_chunks, jobs[j].k_chunks);
+    }
+  }
+  L.g = g;
+  L.n_slabs = n_slabs;
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
   int cur_dev = 0;
   if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
-  bool& attr_done = attr_done_dev[cur_dev];
-  if (!attr_done) {
-    e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS_BYTES);
+  if (!attr_done_dev[cur_dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done_dev[cur_dev] = true;
   }
-  WgradPair pr;
-  pr.job[0] = a;
-  pr.job[1] = b ? *b : a;
-  pr.nwg[0] = wgrad_workgroups(a);
-  pr.nwg[1] = b ? wgrad_workgroups(*b) : 0u;
-  unsigned n_red_wg = 0;
-  pr.red.n_segs = 0;
-  if (red && n_red > 0) {
-    n_red_wg = plan_slab_reduce(red, n_red, pr.red);
-    if (!n_red_wg) return hipErrorInvalidValue;
-  }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(pr.nwg[0] + pr.nwg[1] + n_red_wg), dim3(512), WD_LDS_BYTES, s, pr);
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((L.tiles[0] + L.tiles[1]) * n_slabs)), dim3(512), WD_LDS_BYTES, s, L);
   return hipGetLastError();
 }
 

@@ -66,15 +66,17 @@ struct TrainWs {
   _Float16 *GO[2], *SP, *MELP, *GSP;   // d out plane (per flow parity), spectrogram planes, mel planes, d spect planes
   float *Zpost, *OUT;           // [n_flows][B*L*8]
   float *GZ;                    // [B*L*8]
-  float *slab[2], *slab2[2];    // wgrad slabs (dW1 | dW2 + end x skip), two sets: a layer's slabs are reduced inside the NEXT layer's launch
-  float *part[2], *part2[2], *part3;  // column-sum partials of the two weight-gradient jobs (two sets) / of the row kernels of a flow
+  float *slab[2], *slab2[2];    // blocked wgrad slabs (dW1 | dW2), two sets: a layer's slabs are reduced beside the NEXT layer's launch
+  float *part[2], *part2[2];    // column-sum partials of the two weight-gradient jobs (two sets)
+  float *ext[2], *extb[2];      // d (W_end W_skip) partials [n_slabs][16][C] and their column sums [n_slabs][16]
+  float *slab_up, *part3;       // d upsample slabs (one per phase) / partials of the row kernels of a flow and of d upsample
   size_t plane_c;               // elements of one C-channel plane set
   size_t rows8;                 // B*L*8
   size_t zero_bytes;            // prefix that `fresh` clears (all planes)
   size_t bytes;
 };
 
-TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
+TrainWs carve(const wg_config& c, const RowGeom& g, int n_slabs, char* base) {
   TrainWs w;
   const int C = c.n_channels, FL = c.n_flows * c.n_layers, M8 = c.n_mel_channels * 8;
   const size_t chunk = (size_t)g.R * 64;           // elements of one 64-channel plane
@@ -97,13 +99,17 @@ TrainWs carve(const wg_config& c, const RowGeom& g, char* base) {
   w.Zpost = (float*)take((size_t)c.n_flows * w.rows8 * 4);
   w.OUT = (float*)take((size_t)c.n_flows * w.rows8 * 4);
   w.GZ = (float*)take(w.rows8 * 4);
-  const size_t K1 = 3 * (size_t)C + M8;
+  const int cc = C / 64, mc = M8 / 64;
+  const size_t t1 = (size_t)wgrad_tiles(2 * cc, 3 * cc + mc), t2 = (size_t)wgrad_tiles(cc, cc);
   for (int q = 0; q < 2; ++q) {
-    w.slab[q] = (float*)take((size_t)kPhases * 2 * C * K1 * 4);
-    w.slab2[q] = (float*)take((size_t)kPhases * 4 * (C + 64) * C * 4);          // row_split 4: [128 slabs][(C/64 + 1) * 64][C]
-    w.part[q] = (float*)take((size_t)kPhases * 4 * 2 * (size_t)C * 4);            // bias partials: [slabs][rows]
-    w.part2[q] = (float*)take((size_t)kPhases * 4 * (C + 64) * 4);
+    w.slab[q] = (float*)take((size_t)n_slabs * t1 * kWgradTileFloats * 4);
+    w.slab2[q] = (float*)take((size_t)n_slabs * t2 * kWgradTileFloats * 4);
+    w.part[q] = (float*)take((size_t)n_slabs * 2 * C * 4);
+    w.part2[q] = (float*)take((size_t)n_slabs * C * 4);
+    w.ext[q] = (float*)take((size_t)n_slabs * 16 * C * 4);
+    w.extb[q] = (float*)take((size_t)n_slabs * 16 * 4);
   }
+  w.slab_up = (float*)take((size_t)kPhases * wgrad_tiles(mc, 8) * kWgradTileFloats * 4);
   w.part3 = (float*)take(max_sz(max_sz((size_t)flow_bwd_workgroups(g) * 64, (size_t)start_wgrad_workgroups(g) * 5 * C),
                                 (size_t)kPhases * M8) * 4);
   w.bytes = off;
@@ -118,6 +124,7 @@ struct Ctx {
   int C, FL, M8, K1, nl;
   int n_cu;
   int halves;      // 2: the batch runs as two independent half-batch chains (see setup)
+  int n_slabs;     // row ranges of the weight-gradient launches (see setup)
   bool serial;     // WG_TRAIN_SERIAL=1: everything on the caller's stream (profiling of single kernels, A/B runs)
 };
 
@@ -177,7 +184,22 @@ int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* wo
     const char* se = getenv("WG_TRAIN_SERIAL");
     x.serial = se && *se == '1';
   }
-  x.w = carve(c, x.g, (char*)workspace);
+  // Slabs of the weight-gradient launches (train.hip: wgrad_kernel): a layer's (tiles of d W1 + d W2) x n_slabs workgroups
+  // should be ONE round of one workgroup per CU -- n_slabs = CUs / tiles (config 4: 12 tiles -> 21 slabs = 252 workgroups).
+  {
+    const int cc = c.n_channels / 64, mc = c.n_mel_channels * 8 / 64;
+    const int tiles = wgrad_tiles(2 * cc, 3 * cc + mc) + wgrad_tiles(cc, cc);
+    const long long total_steps = (long long)kPhases * (x.g.Rp / 32);
+    long long ns = x.n_cu / tiles;
+    if (const char* e = getenv("WG_TRAIN_SLABS")) {      // tests: pin the number of slabs
+      const int v = atoi(e);
+      if (v >= 1) ns = v;
+    }
+    if (ns < 1) ns = 1;
+    if (ns > total_steps) ns = total_steps;
+    x.n_slabs = (int)ns;
+  }
+  x.w = carve(c, x.g, x.n_slabs, (char*)workspace);
   if (workspace && x.w.bytes > workspace_bytes) return wg_set_error(WG_ERR_WORKSPACE, "training workspace too small");
   if ((size_t)x.g.R * 128 >= (1ull << 32)) return wg_set_error(WG_ERR_INVALID, "plane too large for 32-bit offsets");
   x.C = c.n_channels;
@@ -225,6 +247,7 @@ SlabSeg make_seg(const float* slabs, int n_slabs, size_t stride, size_t n, float
   SlabSeg g;
   g.slabs = slabs; g.out = out; g.stride = stride; g.n = n; g.n_slabs = n_slabs; g.scale = scale;
   g.row_len = row_len; g.perm = perm;
+  g.blocked = 0; g.m_chunks = 0; g.k_chunks = 0; g.n_groups = 1; g.out_group_stride = 0;
   return g;
 }
 
@@ -457,23 +480,13 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   //  already fills the idle CUs and a second chain measured +0.7 ms per step: off unless WG_TRAIN_BWD_HALVES=2, tests.)
   int bh = 1;
   if (const char* e = getenv("WG_TRAIN_BWD_HALVES")) bh = (atoi(e) == 2) ? x.halves : 1;
-  hipStream_t sB = s, sW = s;
+  hipStream_t sB = s, sW = s, sR = s;
   if (!x.serial) {
     if (bh == 2 && !(sB = wg_internal_aux_stream(h, 0))) return wg_set_error(WG_ERR_HIP, "cannot create the second chain's stream");
     if (!(sW = wg_internal_aux_stream(h, 1))) return wg_set_error(WG_ERR_HIP, "cannot create the weight-gradient stream");
+    if (!(sR = wg_internal_aux_stream(h, 2))) return wg_set_error(WG_ERR_HIP, "cannot create the slab-reduction stream");
   }
-  // Slabs of the weight-gradient jobs (Rp is a multiple of 128 = up to 4 parts of whole 32-row steps).  Every slab is
-  // written once and read once by the reduction, so as few as still fill the chip: the small job (4 tiles at 256
-  // channels) cuts a phase in 2 (256 workgroups) rather than 4.  The big job (22 tiles) keeps one slab per phase:
-  // two phases per workgroup (16 slabs, 352 workgroups of 144 steps) halved its slab bytes but measured 0.8 ms per
-  // step slower in the kernel than it saved in the reduction (config 4, MI355X).
-  const int small_tiles = ((cc + 1 + 3) / 4) * ((cc + 1) / 2);
-  int big_pps = 1;
-  int small_split = (small_tiles * kPhases * 2 >= n_cu) ? 2 : 4;
-  if (const char* e = getenv("WG_TRAIN_SLABS")) {      // tests: "<phases per slab of d W1>,<row split of d W2>"
-    int a_ = 0, b_ = 0;
-    if (sscanf(e, "%d,%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2 || a_ == 4) && (b_ == 1 || b_ == 2 || b_ == 4)) { big_pps = a_; small_split = b_; }
-  }
+  const int n_slabs = x.n_slabs;
   int BNw = wn_block_n(C);
   if (BNw == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)n_cu) BNw = 64;
   if (const char* e = getenv("WG_FORCE_BN")) {
@@ -509,14 +522,16 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   //                    kernel of flow k-2 waits for the last of them (w_flow[k & 1]);
   //   GP, X, T, S, A   one set per layer of the whole model: no reuse inside a call.
   TR_ORDER(order_after(h, s, sW));
-  // A layer's slabs are reduced INSIDE the next layer's weight-gradient launch (third job: its memory-bound workgroups
-  // run beside the MFMA-bound ones), from the slab set the launch before wrote; the last one gets a launch of its own.
-  SlabSeg pend[kMaxSlabSegs];
-  int n_pend = 0, n_layer = 0;
-  // (marks are waited on one or two flows after their record: events of their own, wg_internal_mark_event, slots
-  //  0-7 = w_done[layer], 8-9 = w_flow[parity]; a null entry = not recorded in this call, nothing to wait for)
+  // A layer's slabs are reduced by a launch of its own on a third stream (sR, lowest priority too): it is HBM-bound and
+  // small in registers and LDS, so its workgroups run beside the NEXT layer's weight-gradient workgroups (MFMA / L2-bound,
+  // one per CU).  Two slab sets: launch n + 2 on sW waits for the reduction of launch n (r_done), the reduction of launch
+  // n for launch n itself (l_done).
+  int n_layer = 0;
+  // (marks are waited on one or two flows / launches after their record: events of their own, wg_internal_mark_event,
+  //  slots 0-7 = w_done[layer], 8-9 = w_flow[parity], 10-11 = l_done[set], 12-13 = r_done[set]; a null entry = not recorded
+  //  in this call, nothing to wait for)
   hipEvent_t w_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, w_flow[2] = {nullptr, nullptr};
-  static_assert(sizeof(w_done) / sizeof(w_done[0]) + sizeof(w_flow) / sizeof(w_flow[0]) <= 16, "mark pool too small");
+  hipEvent_t l_done[2] = {nullptr, nullptr}, r_done[2] = {nullptr, nullptr};
   auto mark = [&](hipStream_t st, hipEvent_t& e, int slot) -> hipError_t {
     e = nullptr;
     if (x.serial) return hipSuccess;
@@ -590,58 +605,62 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
       {
         // d W1 = d pre x [x taps | spect]^T, d b1;
         // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
-        // job with the d out plane appended to the d x planes (the last layer has no d x: d out alone).
-        // Both jobs in ONE launch: the short workgroups of the second fill the idle slots of the first one's last round.
-        WgradArgs a, a2;
+        // job with the d out plane as the `extra` 16 rows (the last layer has no d x: the d out plane stands in as the
+        // job's G as well, and that part of the result is not used).
+        // Both jobs in ONE launch over the same slab partition (train.hip: wgrad_kernel).
+        WgradJob jb[2];
         const int set = n_layer & 1;
         ++n_layer;
-        memset(&a, 0, sizeof a);
-        a.G = GPi;
-        a.m_chunks = 2 * cc;
-        a.n_runs = 4;
-        a.run[0] = run_of(Xi, cc, -d);
-        a.run[1] = run_of(Xi, cc, 0);
-        a.run[2] = run_of(Xi, cc, d);
-        a.run[3] = run_of(w.SP, mc, 0);
-        a.k_chunks = 3 * cc + mc;
-        a.g = g;
-        a.row_split = 1;
-        a.phases_per_slab = big_pps;
-        a.out = w.slab[set];
-        a.out_scale = 1.0f;
-        a.bias_out = w.part[set];
-        memset(&a2, 0, sizeof a2);
-        const int gc = gx ? cc : 0;                 // chunks of d x
-        a2.G = gx ? gx : GOk;
-        a2.G_last = gx ? GOk : nullptr;
-        a2.m_chunks = gc + 1;
-        a2.n_runs = 1;
-        a2.run[0] = run_of(Ai, cc, 0);
-        a2.k_chunks = cc;
-        a2.g = g;
-        a2.row_split = small_split;
-        a2.phases_per_slab = 1;
-        a2.out = w.slab2[set];
-        a2.out_scale = 1.0f;
-        a2.bias_out = w.part2[set];
-        TR_PROF(sW, 6, TR_TRY(launch_wgrad(a, &a2, n_pend ? pend : nullptr, n_pend, sW)));
-        // everything this launch left in its slabs: reduced by the next launch (or by the flush at the end of the call)
-        const int ns = kPhases * small_split;
-        const size_t n1 = (size_t)2 * C * K1, slab_n = (size_t)(gc + 1) * 64 * C, bias_n = (size_t)(gc + 1) * 64;
-        n_pend = 0;
-        // (results in NATURAL channel order: perm bit 0 = rows are channels, bit 1 = columns are -- SlabSeg)
-        auto add = [&](const float* slabs, int n_slabs, size_t stride, size_t n, float* out, int row_len, int perm) {
-          pend[n_pend++] = make_seg(slabs, n_slabs, stride, n, inv, out, row_len, perm);
+        memset(jb, 0, sizeof jb);
+        jb[0].G = GPi;
+        jb[0].m_chunks = 2 * cc;
+        jb[0].n_runs = 4;
+        jb[0].run[0] = run_of(Xi, cc, -d);
+        jb[0].run[1] = run_of(Xi, cc, 0);
+        jb[0].run[2] = run_of(Xi, cc, d);
+        jb[0].run[3] = run_of(w.SP, mc, 0);
+        jb[0].k_chunks = 3 * cc + mc;
+        jb[0].slabs = w.slab[set];
+        jb[0].bias_out = w.part[set];
+        jb[1].G = gx ? gx : GOk;
+        jb[1].m_chunks = gx ? cc : 1;
+        jb[1].G_extra = GOk;
+        jb[1].n_runs = 1;
+        jb[1].run[0] = run_of(Ai, cc, 0);
+        jb[1].k_chunks = cc;
+        jb[1].slabs = w.slab2[set];
+        jb[1].bias_out = w.part2[set];
+        jb[1].extra_out = w.ext[set];
+        jb[1].extra_bias_out = w.extb[set];
+        TR_ORDER(wait_for(sW, r_done[set]));          // the reduction of the launch before last has read this slab set
+        TR_PROF(sW, 6, TR_TRY(launch_wgrad(jb, 2, g, n_slabs, sW)));
+        TR_ORDER(mark(sW, l_done[set], 10 + set));
+        // ---- reduction of everything this launch left behind, in NATURAL channel order (SlabSeg: perm bit 0 = rows are
+        // channels, bit 1 = columns are)
+        SlabSeg seg[kMaxSlabSegs];
+        int n_seg = 0;
+        const size_t n1 = (size_t)2 * C * K1;
+        auto add_flat = [&](const float* slabs, size_t stride, size_t n, float* out, int row_len, int perm) {
+          seg[n_seg++] = make_seg(slabs, n_slabs, stride, n, inv, out, row_len, perm);
         };
-        add(w.slab[set], kPhases / big_pps, n1, n1, gr->dw1 + gofs(fl, n1), K1, 3);
-        add(w.part[set], kPhases / big_pps, (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
+        auto add_blocked = [&](const float* slabs, int m_ch, int k_ch, float* out) {
+          SlabSeg q = make_seg(slabs, n_slabs, (size_t)wgrad_tiles(m_ch, k_ch) * kWgradTileFloats,
+                               (size_t)wgrad_tiles(m_ch, k_ch) * kWgradTileFloats, inv, out, k_ch * 64, 3);
+          q.blocked = 1; q.m_chunks = m_ch; q.k_chunks = k_ch; q.n_groups = 1;
+          seg[n_seg++] = q;
+        };
+        add_blocked(w.slab[set], 2 * cc, 3 * cc + mc, gr->dw1 + gofs(fl, n1));
+        add_flat(w.part[set], (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
         if (gx) {
-          add(w.slab2[set], ns, slab_n, (size_t)C * C, gr->dw2 + gofs(fl, (size_t)C * C), C, 3);
-          add(w.part2[set], ns, bias_n, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
+          add_blocked(w.slab2[set], cc, cc, gr->dw2 + gofs(fl, (size_t)C * C));
+          add_flat(w.part2[set], (size_t)C, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
         }
-        add(w.slab2[set] + (size_t)gc * 64 * C, ns, slab_n, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
+        add_flat(w.ext[set], (size_t)16 * C, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
         // d out_init = sum over columns of (d b | d log_s), once per flow
-        if (i == 0) add(w.part2[set] + (size_t)gc * 64, ns, bias_n, 8, gr->dout_init[k], 0, 0);
+        if (i == 0) add_flat(w.extb[set], 16, 8, gr->dout_init[k], 0, 0);
+        TR_ORDER(wait_for(sR, l_done[set]));
+        TR_TRY(launch_slab_reduce_multi(seg, n_seg, sR));
+        TR_ORDER(mark(sR, r_done[set], 12 + set));
         TR_ORDER(mark(sW, w_done[i], i));
       }
       {
@@ -700,9 +719,9 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     const SlabSeg sg = make_seg(w.part3, flow_bwd_workgroups(g), 64, 64, inv, gr->dw1x1[k], 0, 0);
     TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
   }
-  if (n_pend) TR_TRY(launch_slab_reduce_multi(pend, n_pend, sW));     // the last layer's slabs
   if (flow_lo > 0) {                      // the upsample gradient needs the d pre planes of every flow
     TR_ORDER(order_after(h, sW, s));      // every gradient of the call is final on the caller's stream
+    TR_ORDER(order_after(h, sR, s));
     return WG_OK;
   }
   {
@@ -720,25 +739,25 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     TR_TRY(launch_plane_gemm(a, s));
   }
   {
-    WgradArgs a;   // d upsample: per phase, d spect x mel frames q..q-3 (no sum over phases)
+    WgradJob a;   // d upsample: per phase, d spect x mel frames q..q-3 (no sum over phases: one slab = one phase = one result)
     memset(&a, 0, sizeof a);
     a.G = w.GSP;
     a.m_chunks = mc;
     a.n_runs = 4;
     for (int j = 0; j < 4; ++j) a.run[j] = run_of(w.MELP, 2, -32 * j);
     a.k_chunks = 8;
-    a.g = g;
-    a.row_split = 1;
-    a.phases_per_slab = 1;
-    a.out = gr->dwup;
-    a.out_scale = inv;
-    a.natural_rows = 1;
-    a.bias_out = w.part3;                 // (w.part belongs to the weight-gradient stream, still busy with the last layers)
-    TR_TRY(launch_wgrad(a, nullptr, nullptr, 0, s));
-    const SlabSeg sg = make_seg(w.part3, kPhases, M8, M8, inv, gr->dbup, M8, 2);
-    TR_TRY(launch_slab_reduce_multi(&sg, 1, s));
+    a.slabs = w.slab_up;
+    a.bias_out = w.part3;
+    TR_TRY(launch_wgrad(&a, 1, g, kPhases, s));
+    SlabSeg sg[2];
+    const size_t tile_n = (size_t)wgrad_tiles(mc, 8) * kWgradTileFloats;
+    sg[0] = make_seg(w.slab_up, kPhases, tile_n, tile_n, inv, gr->dwup, 512, 1);      // rows to natural order, columns are mel taps
+    sg[0].blocked = 1; sg[0].m_chunks = mc; sg[0].k_chunks = 8; sg[0].n_groups = kPhases; sg[0].out_group_stride = (size_t)M8 * 512;
+    sg[1] = make_seg(w.part3, kPhases, M8, M8, inv, gr->dbup, M8, 2);
+    TR_TRY(launch_slab_reduce_multi(sg, 2, s));
   }
   TR_ORDER(order_after(h, sW, s));        // every gradient of the call is final on the caller's stream
+  TR_ORDER(order_after(h, sR, s));
   return WG_OK;
 }
 

@@ -41,24 +41,48 @@ struct PGemmArgs {
   _Float16* o0;             // output planes [M/64][R][64]
 };
 
-// dW[m][k'] = sum over the rows of one slab of G[row][m] * X[row(+shift)][k']  -> out[slab][m][k'] * out_scale
-// slab = phase * row_split + part: a phase's Rp rows are cut into row_split parts (small GEMMs: more workgroups);
-// or slab = phase / phases_per_slab (large GEMMs: fewer, longer workgroups -- half the slab bytes to write and reduce)
-struct WgradArgs {
-  const _Float16* G;        // planes [m_chunks][R][64]  (the last chunk comes from G_last when that is set)
-  const _Float16* G_last;   // optional: one more 64-channel plane appended to G (e.g. the d out plane behind d x)
-  int m_chunks;             // chunks in all, G_last included
+// Weight gradient dW[m][k'] = sum over rows of G[row][m] * X[row (+ shift)][k'] (train.hip: wgrad_kernel).
+// The rows (32 phases x Rp) are cut into n_slabs contiguous ranges of 32-row steps (a range may cross phase boundaries);
+// one workgroup = one output tile x one slab; it leaves its fp32 partial tile in `slabs` in BLOCKED order (the order of
+// its accumulator registers: every store instruction writes one contiguous KiB) and slab_reduce sums the slabs and
+// un-blocks.  Tiles: 256 x 256 (4 x 4 chunks of 64) over the whole multiples of 4 K'-chunks, then 512 x 128 (8 x 2)
+// over the remaining 1-3 K'-chunks (wgrad_tile below: the same decode on the host, in the kernel and in the reduction).
+struct WgradJob {
+  const _Float16* G;        // planes [m_chunks][R][64]
+  int m_chunks;
+  const _Float16* G_extra;  // optional: one more 64-channel plane whose first 16 channels give 16 extra output rows
+                            // (the d out plane behind d x: d (W_end W_skip) shares the acts operand with d W_res)
   PRun run[kMaxRuns];       // the X operand (same runs as the forward GEMM's B operand)
   int n_runs;
   int k_chunks;             // sum n_chunks
-  RowGeom g;
-  int row_split;            // 1, 2 or 4
-  int phases_per_slab;      // 1, or (row_split == 1 only) 2 / 4: one workgroup runs that many consecutive phases into one slab
-  float* out;               // [32*row_split/phases_per_slab slabs][m_chunks*64][k_chunks*64] fp32
-  float out_scale;
-  float* bias_out;          // optional [slabs][m_chunks*64]: sum over the slab's rows of G (bias gradients), unscaled
-  int natural_rows;         // 1: `out` is a final result (no reduction follows): its rows m go to natural channel order
+  float* slabs;             // [n_slabs][wgrad_tiles][kWgradTileFloats] blocked partial tiles
+  float* bias_out;          // optional [n_slabs][m_chunks*64]: sum over the slab's rows of G (bias gradients)
+  float* extra_out;         // with G_extra: [n_slabs][16][k_chunks*64]
+  float* extra_bias_out;    // with G_extra, optional: [n_slabs][16]
 };
+constexpr int kWgradTileFloats = 8 * 32 * 64 * 4;   // 8 waves x 32 accumulator quads x 64 lanes x 4 = 256 KB
+struct WgradTile {
+  int shape;                // 0: 4 G chunks x 4 X chunks (waves 2 x 4); 1: 8 x 2 (waves 4 x 2); a wave owns 2 x 1 chunks
+  int mc0, kc0;             // first G / X chunk
+  int bias_duty;            // this tile's workgroups also sum G over the rows (done once per G chunk)
+  int extra_duty;           // ... and multiply G_extra with their X chunks (done once per X chunk)
+};
+__host__ __device__ inline int wgrad_tiles(int m_chunks, int k_chunks) {
+  const int gyA = k_chunks / 4, rem = k_chunks - 4 * gyA;
+  return ((m_chunks + 3) / 4) * gyA + ((m_chunks + 7) / 8) * ((rem + 1) / 2);
+}
+__host__ __device__ inline WgradTile wgrad_tile(int m_chunks, int k_chunks, int t) {
+  const int gxA = (m_chunks + 3) / 4, gyA = k_chunks / 4, nA = gxA * gyA, gxB = (m_chunks + 7) / 8;
+  WgradTile q;
+  if (t < nA) {
+    const int by = t / gxA, bx = t - by * gxA;
+    q.shape = 0; q.mc0 = 4 * bx; q.kc0 = 4 * by; q.bias_duty = by == 0; q.extra_duty = bx == 0;
+  } else {
+    const int u = t - nA, by = u / gxB, bx = u - by * gxB;
+    q.shape = 1; q.mc0 = 8 * bx; q.kc0 = 4 * gyA + 2 * by; q.bias_duty = gyA == 0 && by == 0; q.extra_duty = bx == 0;
+  }
+  return q;
+}
 
 // Row kernels of the flow backward (coupling, 1x1, start): model.py:200-218 differentiated.
 struct FlowBwdArgs {
@@ -109,15 +133,14 @@ struct PackArgs {
   size_t n_pieces;                    // 16-byte output pieces
 };
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
-// one launch for job `a` and, optionally, a second job `b` whose workgroups fill the slots a's last round leaves idle and a
-// slab reduction `red` (of slabs an earlier launch wrote) whose memory-bound workgroups run beside them
-struct SlabSeg;
-hipError_t launch_wgrad(const WgradArgs& a, const WgradArgs* b, const SlabSeg* red, int n_red, hipStream_t s);
+// one launch for up to two jobs (a layer's d W1 and its d W2 / end x skip: their tiles share the slab partition, so
+// (tiles of both) x n_slabs workgroups fill the chip in ONE round when n_slabs = CUs / tiles)
+hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int n_slabs, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n  (fixed order: bitwise reproducible), for up to
 // kMaxSlabSegs independent (slabs, out) pairs in ONE launch: a layer's weight-gradient
 // launches leave six small-to-large slab sets behind, and six launches of a few microseconds each cost more in launch
 // gaps than in traffic
-constexpr int kMaxSlabSegs = 6;
+constexpr int kMaxSlabSegs = 8;
 struct SlabSeg {
   const float* slabs;
   float* out;
@@ -128,6 +151,11 @@ struct SlabSeg {
   // (wg_common.h: pos_to_chan, a permutation inside 32-blocks that keeps aligned runs of four together, so a float4 of
   // positions is a float4 of channels): perm bit 0 = the rows are channels, bit 1 = the columns are.  row_len = 0: flat.
   int row_len, perm;
+  // blocked = 1: the slabs are wgrad_kernel's blocked tiles (WgradJob::slabs): n = tiles * kWgradTileFloats, (m_chunks,
+  // k_chunks) decode a float4's (row, 4 columns), row_len = k_chunks * 64; the result is n_groups matrices (at
+  // out + group * out_group_stride), each the sum of n_slabs / n_groups consecutive slabs (groups > 1: d upsample, one per phase)
+  int blocked, m_chunks, k_chunks, n_groups;
+  size_t out_group_stride;
 };
 hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t s);
 hipError_t launch_mel_plane(const void* mel, int io_f16, int M, const RowGeom& g, _Float16* melp, hipStream_t s);
