@@ -219,6 +219,8 @@ struct Prof {
 
 }  // namespace
 
+namespace wg { extern unsigned long long* g_wgrad_stamps; }   // train.hip
+
 int wg_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 
 // accessors for the other translation units of the library (train_api.cpp)
@@ -925,6 +927,7 @@ double wg_macs_per_group_step(const wg_handle* h) {
 int wg_debug_set_stamp_buffer(wg_handle* h, void* device_buffer) {
   if (!h) return fail(WG_ERR_INVALID, "null handle");
   h->dbg_stamps = (unsigned long long*)device_buffer;
+  wg::g_wgrad_stamps = (unsigned long long*)device_buffer;
   return WG_OK;
 }
 

@@ -474,57 +474,57 @@ struct WgradLaunch {
   int tiles[2];           // tiles of each job (the second may be 0)
   RowGeom g;
   int n_slabs;
+  unsigned long long* stamps;   // diagnostic builds only (-DWGR_STAMPS): [workgroups][8]
 };
+#ifdef WGR_STAMPS
+#define WGR_STAMP(j) do { if (tid == 0 && L.stamps) L.stamps[(size_t)blockIdx.x * 8 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WGR_STAMP(j) do { } while (0)
+#endif
 }  // namespace
 
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad_kernel(const WgradLaunch L) {
-  extern __shared__ __attribute__((aligned(1024))) _Float16 wg_smem[];
+// The body, specialised by tile shape and by the extra plane: everything the step loop needs is then a compile-time
+// constant or sits in a register.  (The first version of this kernel decided all of it at run time inside the loop --
+// which slices to stage, a 7-way switch for the vmcnt immediate, per-fragment bias conditions: 320 scalar instructions
+// and 61 branches per step, 1 900 cycles of scalar issue per wave beside 512 cycles of MFMA.)
+template <bool SHAPE_B, bool EXTRA>
+__device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob& a, const WgradTile tl, const int slab,
+                                           const int tile, const int job_tiles, _Float16* wg_smem) {
+  constexpr int MC = SHAPE_B ? 8 : 4, KCW = SHAPE_B ? 2 : 4;
+  constexpr int NS = (MC + KCW) / 2;              // staging pieces per wave and step; waves 0-3 one more with EXTRA
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const RowGeom& g = L.g;
-  const int T = L.tiles[0] + L.tiles[1];
-  const unsigned wgid = xcd_order(blockIdx.x, gridDim.x);
-  const int slab = (int)(wgid / (unsigned)T), tt = (int)(wgid - (unsigned)slab * (unsigned)T);
-  const bool second = tt >= L.tiles[0];
-  const WgradJob& a = second ? L.job[1] : L.job[0];
-  const int tile = second ? tt - L.tiles[0] : tt;
-  const WgradTile tl = wgrad_tile(a.m_chunks, a.k_chunks, tile);
-  const int MC = tl.shape ? 8 : 4, KCW = tl.shape ? 2 : 4;
-  const int wm = tl.shape ? (w >> 1) : (w >> 2), wk = tl.shape ? (w & 1) : (w & 3);
-  const bool do_extra = tl.extra_duty && a.G_extra != nullptr;
+  const int wm = SHAPE_B ? (w >> 1) : (w >> 2), wk = SHAPE_B ? (w & 1) : (w & 3);
   const bool do_bias = tl.bias_duty && a.bias_out != nullptr;
   const size_t R64 = (size_t)g.R * 64;
+  const int m_chunks = a.m_chunks, k_chunks = a.k_chunks;
 
-  // ---- staging duty of this wave: 8-row block rb of slices (w >> 2) + 2 j.  Slices past the matrix are not staged:
-  // the fragments read from them are garbage, and so are the accumulators they feed, which are never stored.
+  // ---- staging duty of this wave: 8-row block rb of slices (w >> 2) + 2 j.  A slice past the matrix is staged from
+  // the job's first chunk instead (every wave issues the same number of pieces: the vmcnt immediates depend on it);
+  // the accumulators it feeds are never stored.
   const int rb = w & 3;
-  const _Float16* sbase[WD_MAX_DMA];
-  int sdt[WD_MAX_DMA];
-  bool son[WD_MAX_DMA];
-  int nsw = 0;
+  const _Float16* sbase[NS + 1];
+  int sdt[NS + 1];
 #pragma unroll
-  for (int j = 0; j < WD_MAX_DMA; ++j) {
+  for (int j = 0; j < NS + 1; ++j) {
     const int sl = (w >> 2) + 2 * j;
     sbase[j] = a.G;
     sdt[j] = 0;
-    son[j] = false;
     if (sl < MC) {
-      son[j] = tl.mc0 + sl < a.m_chunks;
-      sbase[j] = a.G + (size_t)(son[j] ? tl.mc0 + sl : 0) * R64;
+      if (tl.mc0 + sl < m_chunks) sbase[j] = a.G + (size_t)(tl.mc0 + sl) * R64;
     } else if (sl < MC + KCW) {
       int c = tl.kc0 + (sl - MC);
-      son[j] = c < a.k_chunks;
-      if (son[j]) {
+      if (c < k_chunks) {
         int i = 0;
         while (c >= a.run[i].n_chunks) { c -= a.run[i].n_chunks; ++i; }
         sbase[j] = a.run[i].base + (size_t)c * R64;
         sdt[j] = a.run[i].dt;
       }
-    } else if (sl == MC + KCW) {
-      son[j] = do_extra;
-      if (do_extra) sbase[j] = a.G_extra;
+    } else if (EXTRA) {
+      sbase[j] = a.G_extra;
     }
-    nsw += son[j] ? 1 : 0;
   }
+  const bool sixth = EXTRA && w < 4;              // this wave also stages a piece of the extra slice (j = NS)
   // lane -> (row lr of the 8-row block, 16-byte slot): fetches piece slot ^ (key << 1) of its row, key = (row >> 1) & 3
   const int lr = lane >> 3;
   const unsigned voff = (unsigned)(lr * 128 + (((lane & 7) ^ (((lr >> 1) & 3) << 1)) << 4));
@@ -537,24 +537,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int gs0 = (int)((long long)slab * total / L.n_slabs), gs1 = (int)((long long)(slab + 1) * total / L.n_slabs);
   const int n_steps = gs1 - gs0;
 
-  const char* src[WD_MAX_DMA];
-  auto set_phase = [&](int p) {
+  const char* src[NS + 1];                        // running source pointers: + 4 KiB per step inside a phase
+  int ip = gs0 / spp, ist = gs0 - ip * spp;       // cursor of the next step to stage
+  auto set_phase = [&](int p, int st0) {
 #pragma unroll
-    for (int j = 0; j < WD_MAX_DMA; ++j)
-      src[j] = uniform_ptr(sbase[j] + (shifted_row(g, p, sdt[j]) + (size_t)(8 * rb)) * 64);
+    for (int j = 0; j < NS + 1; ++j)
+      src[j] = uniform_ptr(sbase[j] + (shifted_row(g, p, sdt[j]) + (size_t)(8 * rb) + (size_t)st0 * WG_STEP) * 64);
   };
-  int ip = gs0 / spp, ist = gs0 - ip * spp;     // cursor of the next step to stage
-  set_phase(ip);
-  auto issue = [&](int n) {                      // stage step n of this workgroup (the cursor's step)
-    const unsigned base = lds_u + (unsigned)(n % WD_STAGES) * WD_STAGE_BYTES;
-    const size_t ro = (size_t)ist * (WG_STEP * 128);
+  set_phase(ip, ist);
+  unsigned lds_w = lds_u;                         // LDS address of this wave's first piece in the stage being filled
+  auto issue = [&]() {                            // stage the cursor's step into the next ring stage
 #pragma unroll
-    for (int j = 0; j < WD_MAX_DMA; ++j)
-      if (son[j]) tr_glds16(src[j] + ro, voff, base + (unsigned)j * 8192u);
+    for (int j = 0; j < NS; ++j) {
+      tr_glds16(src[j], voff, lds_w + (unsigned)j * 8192u);
+      src[j] += WG_STEP * 128;
+    }
+    if (sixth) {
+      tr_glds16(src[NS], voff, lds_w + (unsigned)NS * 8192u);
+      src[NS] += WG_STEP * 128;
+    }
+    lds_w = (lds_w == lds_u + 2u * WD_STAGE_BYTES) ? lds_u : lds_w + WD_STAGE_BYTES;
     if (++ist == spp) {
       ist = 0;
-      ++ip;
-      if (ip < kPhases) set_phase(ip);
+      if (++ip < kPhases) set_phase(ip, 0);
     }
   };
 
@@ -575,15 +580,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // transposing fragment reads: operand lane (u = lane & 15, g16 = lane >> 4) needs 8 k values of channel u of a
   // 16-channel block; k = 8 g16 + j is tile row 4 g16 + j (j < 4) / 16 + 4 g16 + j - 4 (j >= 4) -- both operands use the
   // same map.  The lane's read starts at tile row 4 g16 + (u >> 2), halves 4 (u & 3) of the block, which sits at
-  // block position i ^ key(row); the second read is 16 rows further (same key).
+  // block position i ^ key(row); the second read is 16 rows further (same key).  Per stage the wave keeps four read
+  // bases for its G slices and four for its X slice; everything else is an immediate offset of the read.
   const int g16 = lane >> 4, u = lane & 15;
   const int tr_row = 4 * g16 + (u >> 2);
   const int tr_key = (tr_row >> 1) & 3;
-  int tr_off[4];   // halves, inside a [32 rows][64] slice
+  int gbase[4], xbase[4];   // halves from wg_smem, stage 0
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tr_off[i] = tr_row * 64 + ((i ^ tr_key) << 4) + 4 * (u & 3);
-  auto frag = [&](const _Float16* slice, int i) -> half8 {
-    const _Float16* q0 = slice + tr_off[i];
+  for (int i = 0; i < 4; ++i) {
+    const int off = tr_row * 64 + ((i ^ tr_key) << 4) + 4 * (u & 3);
+    gbase[i] = (2 * wm) * 2048 + off;
+    xbase[i] = (MC + wk) * 2048 + off;
+  }
+  auto frag_at = [&](const _Float16* q0) -> half8 {
     const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)q0);
     const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 16 * 64));
     const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
@@ -597,68 +606,147 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int j = 0; j < 8; ++j) o[j] = v;
     return o;
   };
-
-  if (n_steps > 0) issue(0);
-  if (n_steps > 1) issue(1);
-  for (int st = 0; st < n_steps; ++st) {
-    tr_wait_keep(st + 1 < n_steps ? nsw : 0);                           // this wave's pieces of step st have landed
-    __syncthreads();                                                  // everyone's have; stage (st + 2) % 3 is free
-    if (st + 2 < n_steps) issue(st + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    const _Float16* stage = wg_smem + (size_t)(st % WD_STAGES) * (WD_STAGE_BYTES / 2);
-    const _Float16* gt = stage + (2 * wm) * 2048;             // this wave's two G slices
-    const _Float16* xt = stage + (MC + wk) * 2048;            // ... and its X slice
-    half8 af[8], bf[2], ef;
-    bf[0] = frag(xt, 0);
+  // Column sums: fragments i = wk (mod KCW) of this wave's G rows are summed by this wave (bit i), the extra plane's by
+  // wave (0, 0) (bit 8).  A fragment of a slice past the matrix is never summed.
+  unsigned bias_mask = 0;
+  if (do_bias) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = frag(gt + (i >> 2) * 2048, i & 3);
-    if (do_extra && wm == 0) ef = frag(stage + (MC + KCW) * 2048, 0);
+    for (int i = 0; i < 8; ++i)
+      if ((i & (KCW - 1)) == wk && tl.mc0 + 2 * wm + (i >> 2) < m_chunks) bias_mask |= 1u << i;
+  }
+  const bool extra_wave = EXTRA && wm == 0;
+  if (extra_wave && wk == 0 && a.extra_bias_out) bias_mask |= 256u;
+  bias_mask = __builtin_amdgcn_readfirstlane(bias_mask);
+
+  // Two waves share a SIMD (w and w + 4), run the same program and meet at one barrier per step: left alone they read
+  // their fragments together (matrix pipe idle) and then queue for the matrix pipe together.  So the second half of the
+  // workgroup runs its MFMAs of step st - 1 AFTER the barrier of step st, from fragments it read before that barrier,
+  // while the first half reads; then the halves swap (MI355X_MICROARCH.md, "Two waves per SIMD", item 9: split by wave
+  // number >= 4).  All 12 fragments of a step live in registers.
+  const bool late = w >= 4;
+  half8 af[8], bf[4], ef;
+  const _Float16* rd = wg_smem;                   // stage being read
+  auto read_all = [&]() {
+    bf[0] = frag_at(rd + xbase[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = frag_at(rd + gbase[i & 3] + (i >> 2) * 2048);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) bf[k] = frag_at(rd + xbase[k]);
+    if (extra_wave) ef = frag_at(rd + gbase[0] + (MC + KCW) * 2048);     // (wm = 0: gbase[0] is the block-0 offset)
+    rd = (rd == wg_smem + 2 * (WD_STAGE_BYTES / 2)) ? wg_smem : rd + WD_STAGE_BYTES / 2;
+  };
+  auto mfma_all = [&]() {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (k < 3) bf[(k + 1) & 1] = frag(xt, k + 1);
-      __builtin_amdgcn_sched_barrier(0);
+#ifdef WGR_NOMFMA      // diagnostic builds: one VALU instruction per fragment pair keeps the LDS reads alive
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k & 1], af[i], acc[i][k], 0, 0, 0);
-      if (do_extra && wm == 0) acce[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k & 1], ef, acce[k], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i) acc[i][k][0] += (float)af[i][0] * (float)bf[k][0];
+#else
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k], af[i], acc[i][k], 0, 0, 0);
+#endif
     }
-    if (do_bias) {      // fragments i = wk (mod KCW) of this wave's row are summed by this wave: one MFMA each
+    if (extra_wave) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acce[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k], ef, acce[k], 0, 0, 0);
+    }
+    if (bias_mask) {    // one MFMA per fragment this wave sums
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if ((i & (KCW - 1)) == wk && tl.mc0 + 2 * wm + (i >> 2) < a.m_chunks)     // (an unstaged slice may hold NaN: 0 x NaN)
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(i), af[i], accb, 0, 0, 0);
+        if (bias_mask & (1u << i)) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(i), af[i], accb, 0, 0, 0);
+      if (bias_mask & 256u) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(8), ef, accb, 0, 0, 0);
     }
-    if (do_extra && wm == 0 && wk == 0 && a.extra_bias_out) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(8), ef, accb, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  WGR_STAMP(1);
+  if (n_steps > 0) issue();
+  if (n_steps > 1) issue();
+  for (int st = 0; st < n_steps; ++st) {
+#ifdef WGR_STAMPS
+    if (st == 1) WGR_STAMP(2);
+    if (st == n_steps / 2) WGR_STAMP(3);
+#endif
+    // this wave's pieces of step st have landed: all but the NS youngest (waves with NS + 1 pieces per step wait for the
+    // oldest piece of step st + 1 as well, issued a whole step ago)
+#ifdef WGR_NODMA
+    if (st < WD_STAGES) tr_wait_vm<0>();
+#else
+    if (st + 1 < n_steps) tr_wait_vm<NS>(); else tr_wait_vm<0>();
+#endif
+#ifndef WGR_NOBAR
+    __syncthreads();                                                  // everyone's have; stage (st + 2) % 3 is free
+#endif
+#ifdef WGR_NODMA       // diagnostic builds (A/B timing only, results are garbage): the ring is filled once and never again
+    if (st + 2 < n_steps && st + 2 < WD_STAGES) issue();
+#else
+    if (st + 2 < n_steps) issue();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (late && st > 0) mfma_all();      // step st - 1, from the fragments read before this barrier
+    read_all();
+    if (!late) mfma_all();
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (late && n_steps > 0) mfma_all();
 
+  WGR_STAMP(4);
   // ---- epilogue.  D: row = 4 * (lane >> 4) + reg = K' inside a 16-block, col = lane & 15 = m inside a 16-block
-  const int Mtot = a.m_chunks * 64, Ktot = a.k_chunks * 64;
+  const int Mtot = m_chunks * 64, Ktot = k_chunks * 64;
   const int kch = tl.kc0 + wk;
-  float4* dst = (float4*)(a.slabs + ((size_t)slab * (second ? L.tiles[1] : L.tiles[0]) + tile) * kWgradTileFloats) + (size_t)w * 32 * 64 + lane;
-  if (kch < a.k_chunks) {
+  float4* dst = (float4*)(a.slabs + ((size_t)slab * job_tiles + tile) * kWgradTileFloats) + (size_t)w * 32 * 64 + lane;
+  if (kch < k_chunks) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (tl.mc0 + 2 * wm + (i >> 2) >= a.m_chunks) continue;
+      if (tl.mc0 + 2 * wm + (i >> 2) >= m_chunks) continue;
 #pragma unroll
       for (int k = 0; k < 4; ++k) dst[(i * 4 + k) * 64] = make_float4(acc[i][k][0], acc[i][k][1], acc[i][k][2], acc[i][k][3]);
     }
-    if (do_extra && wm == 0) {
+    if (extra_wave) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         *(float4*)(a.extra_out + ((size_t)slab * 16 + u) * Ktot + (size_t)kch * 64 + 16 * k + 4 * g16) =
             make_float4(acce[k][0], acce[k][1], acce[k][2], acce[k][3]);
     }
   }
-  if (do_bias) {       // the sum of fragment i sits in accumulator row i: lane group i >> 2, register i & 3
+  // the sum of fragment i sits in accumulator row i: lane group i >> 2, register i & 3
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int mch = tl.mc0 + 2 * wm + (i >> 2);
-      if ((i & (KCW - 1)) == wk && mch < a.m_chunks && g16 == (i >> 2))
-        a.bias_out[(size_t)slab * Mtot + mch * 64 + 16 * (i & 3) + u] = accb[i & 3];
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int mch = tl.mc0 + 2 * wm + (i >> 2);
+    if ((bias_mask & (1u << i)) && g16 == (i >> 2)) a.bias_out[(size_t)slab * Mtot + mch * 64 + 16 * (i & 3) + u] = accb[i & 3];
   }
-  if (do_extra && wm == 0 && wk == 0 && a.extra_bias_out && g16 == 2) a.extra_bias_out[(size_t)slab * 16 + u] = accb[0];
+  if ((bias_mask & 256u) && g16 == 2) a.extra_bias_out[(size_t)slab * 16 + u] = accb[0];
+#ifdef WGR_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WGR_STAMP(5);
+  if (tid == 0 && L.stamps) {
+    L.stamps[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)tile << 32) | (unsigned)slab;
+    L.stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)n_steps << 32);
+  }
+#endif
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad_kernel(const WgradLaunch L) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 wg_smem[];
+#ifdef WGR_STAMPS
+  const int tid = threadIdx.x;
+#endif
+  WGR_STAMP(0);
+  const int T = L.tiles[0] + L.tiles[1];
+  const unsigned wgid = xcd_order(blockIdx.x, gridDim.x);
+  const int slab = (int)(wgid / (unsigned)T), tt = (int)(wgid - (unsigned)slab * (unsigned)T);
+  const bool second = tt >= L.tiles[0];
+  const WgradJob& a = second ? L.job[1] : L.job[0];
+  const int tile = second ? tt - L.tiles[0] : tt, job_tiles = second ? L.tiles[1] : L.tiles[0];
+  const WgradTile tl = wgrad_tile(a.m_chunks, a.k_chunks, tile);
+  const bool extra = tl.extra_duty && a.G_extra != nullptr;
+  if (tl.shape) {
+    if (extra) wgrad_body<true, true>(L, a, tl, slab, tile, job_tiles, wg_smem);
+    else wgrad_body<true, false>(L, a, tl, slab, tile, job_tiles, wg_smem);
+  } else {
+    if (extra) wgrad_body<false, true>(L, a, tl, slab, tile, job_tiles, wg_smem);
+    else wgrad_body<false, false>(L, a, tl, slab, tile, job_tiles, wg_smem);
+  }
 }
 
 namespace {
@@ -671,6 +759,8 @@ hipError_t check_wgrad(const WgradJob& a) {
   return hipSuccess;
 }
 }  // namespace
+
+unsigned long long* g_wgrad_stamps = nullptr;     // diagnostic builds: set through wg_debug_set_stamp_buffer
 
 hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int n_slabs, hipStream_t s) {
   if (n_jobs < 1 || n_jobs > 2 || g.Rp % WG_STEP || n_slabs < 1 || (long long)n_slabs > (long long)kPhases * (g.Rp / WG_STEP))
@@ -687,6 +777,7 @@ hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int 
   }
   L.g = g;
   L.n_slabs = n_slabs;
+  L.stamps = g_wgrad_stamps;
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
   int cur_dev = 0;
   if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
