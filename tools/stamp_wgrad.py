@@ -25,12 +25,12 @@ for _ in range(2):
   model.zero_grad(set_to_none=True)
   crit(model((mel, wav)), None).backward()
 eng = model._engine
-buf = torch.zeros(1024 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(1024 * 32, dtype=torch.int64, device="cuda")
 eng.lib.wg_debug_set_stamp_buffer(eng.handle, buf.data_ptr())
 model.zero_grad(set_to_none=True)
 crit(model((mel, wav)), None).backward()
 torch.cuda.synchronize()
-st = buf.view(1024, 8).cpu().numpy().astype(np.int64)
+st = buf.view(1024, 32).cpu().numpy().astype(np.int64)
 st = st[st[:, 0] != 0]
 print("workgroups stamped", len(st))
 t0 = st[:, 0].min()
@@ -49,3 +49,12 @@ for t in sorted(set(tile)):
   m = tile == t
   print(f"tile {t:2d}: n {m.sum():3d} per-step median {np.median(per_step[m]):7.0f} max {per_step[m].max():7.0f}  epilogue median {np.median((rel[:, 5] - rel[:, 4])[m]):7.0f}"
         f"  first-half/second-half per step {np.median(((rel[:, 3] - rel[:, 2]) / np.maximum(nst // 2 - 1, 1))[m]):7.0f} / {np.median(((rel[:, 4] - rel[:, 3]) / np.maximum(nst - nst // 2, 1))[m]):7.0f}")
+
+names = ["top", "vmcnt done", "barrier passed", "DMA issued", "late MFMA done", "reads issued", "early MFMA done"]
+for label, o in (("wave 0 (early half)", 8), ("wave 4 (late half)", 16)):
+  d = st[:, o:o + 7]
+  ok = (d[:, 0] != 0) & (tile >= 2) & (tile <= 9)
+  print(label, "step 10, tiles 2-9, cycles since the step's top (median / p90):")
+  for j in range(1, 7):
+    c = (d[ok, j] - d[ok, 0])
+    print(f"   {names[j]:18s} {int(np.median(c)):6d} / {int(np.percentile(c, 90)):6d}")

@@ -477,9 +477,12 @@ struct WgradLaunch {
   unsigned long long* stamps;   // diagnostic builds only (-DWGR_STAMPS): [workgroups][8]
 };
 #ifdef WGR_STAMPS
-#define WGR_STAMP(j) do { if (tid == 0 && L.stamps) L.stamps[(size_t)blockIdx.x * 8 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WGR_STAMP(j) do { if (tid == 0 && L.stamps) L.stamps[(size_t)blockIdx.x * 32 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+// inside step 10: wave 0 (early half) -> slots 8.., wave 4 (late half) -> slots 16..
+#define WGR_STEP_STAMP(j) do { if (st == 10 && lane == 0 && (w == 0 || w == 4) && L.stamps) L.stamps[(size_t)blockIdx.x * 32 + 8 + 2 * w + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WGR_STAMP(j) do { } while (0)
+#define WGR_STEP_STAMP(j) do { } while (0)
 #endif
 }  // namespace
 
@@ -669,23 +672,38 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
 #endif
     // this wave's pieces of step st have landed: all but the NS youngest (waves with NS + 1 pieces per step wait for the
     // oldest piece of step st + 1 as well, issued a whole step ago)
+    WGR_STEP_STAMP(0);
 #ifdef WGR_NODMA
     if (st < WD_STAGES) tr_wait_vm<0>();
 #else
     if (st + 1 < n_steps) tr_wait_vm<NS>(); else tr_wait_vm<0>();
 #endif
+    WGR_STEP_STAMP(1);
 #ifndef WGR_NOBAR
     __syncthreads();                                                  // everyone's have; stage (st + 2) % 3 is free
 #endif
+    WGR_STEP_STAMP(2);
+    // Staging costs the issuing wave 100+ cycles per piece (in-kernel stamps: 350-530 cycles for a wave's 4-5 pieces when
+    // all eight waves issue together right behind the barrier), so the late half runs its MFMAs FIRST -- the matrix pipe
+    // starts at the barrier -- and stages afterwards, while the early half stages and reads.
 #ifdef WGR_NODMA       // diagnostic builds (A/B timing only, results are garbage): the ring is filled once and never again
-    if (st + 2 < n_steps && st + 2 < WD_STAGES) issue();
+    const bool stage_now = st + 2 < n_steps && st + 2 < WD_STAGES;
 #else
-    if (st + 2 < n_steps) issue();
+    const bool stage_now = st + 2 < n_steps;
 #endif
+    if (!late && stage_now) issue();
     __builtin_amdgcn_sched_barrier(0);
-    if (late && st > 0) mfma_all();      // step st - 1, from the fragments read before this barrier
+    WGR_STEP_STAMP(3);
+    if (late) {
+      if (st > 0) mfma_all();            // step st - 1, from the fragments read before this barrier
+      if (stage_now) issue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WGR_STEP_STAMP(4);
     read_all();
-    if (!late) mfma_all();
+    WGR_STEP_STAMP(5);
+    if (!late) mfma_all();                 // (measured: the early half reading before it stages is 3 % slower)
+    WGR_STEP_STAMP(6);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (late && n_steps > 0) mfma_all();
@@ -720,8 +738,8 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WGR_STAMP(5);
   if (tid == 0 && L.stamps) {
-    L.stamps[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)tile << 32) | (unsigned)slab;
-    L.stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)n_steps << 32);
+    L.stamps[(size_t)blockIdx.x * 32 + 6] = ((unsigned long long)tile << 32) | (unsigned)slab;
+    L.stamps[(size_t)blockIdx.x * 32 + 7] = ((unsigned long long)n_steps << 32);
   }
 #endif
 }
