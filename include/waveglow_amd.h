@@ -124,6 +124,12 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
 int wg_loss(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
             const float* log_det_W, float sigma, float* loss_out, void* workspace, size_t workspace_bytes,
             void* stream);
+/* The same with log_det_W as n_flows DEVICE floats: nothing of the loss passes through the host, so a training step
+ * needs no stream synchronisation between forward and backward (the reference reads the 12 scalars as tensors too,
+ * train.py:37-41). */
+int wg_loss_dev(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
+                const float* log_det_W_dev, float sigma, float* loss_out, void* workspace, size_t workspace_bytes,
+                void* stream);
 
 /* Algorithmic MACs per group-timestep (8 samples) of one infer pass, as SURVEY.md section 8(d) counts
  * them (for roofline reporting). */
@@ -242,6 +248,30 @@ typedef struct wg_train_plain {
  * gate pre-scales and fragment orders above in one pass per tensor.  Not differentiable -- the gradients come back in
  * natural order (wg_train_grads).  Enqueue-only. */
 int wg_train_pack(wg_handle* h, const wg_train_plain* in, const wg_train_weights* out, void* stream);
+
+/* ---- Training plumbing on the device (round 3): the module's OWN parameter tensors in, one gradient per parameter out.
+ * Replaces wg_train_plain / wg_train_pack plus the caller-side autograd ops around them (weight norm, stacking, the
+ * W_end x W_skip fold and their backward): reference modules WN.start / in_layers / cond_layer / res_skip_layers
+ * (torch weight_norm: w = g v / ||v||, model.py:85-113), WN.end (model.py:90-92), Invertible1x1Conv.conv
+ * (model.py:29-43), WaveGlow.upsample (model.py:145-150).
+ * The parameters come in the library's canonical order: wg_train_param_count / _name (the state_dict key of the
+ * reference's module tree: "...parametrizations.weight.original0|1" for weight-normed modules, "...weight" otherwise,
+ * weight_normed selects which) / _numel.  All tensors fp32, contiguous, in their native layouts. */
+int32_t wg_train_param_count(const wg_handle* h, int32_t weight_normed);
+const char* wg_train_param_name(const wg_handle* h, int32_t weight_normed, int32_t i);   /* valid until the next call on this thread */
+int64_t wg_train_param_numel(const wg_handle* h, int32_t weight_normed, int32_t i);
+/* Scratch the two calls below share (row norms, W_end x W_skip, pointer tables): must stay untouched between a
+ * wg_train_prepare and the wg_train_param_grads of the same step. */
+size_t wg_train_prepare_bytes(const wg_handle* h);
+/* Fills EVERY member of *out (fragment tensors and the small fp32 vectors; all buffers caller-allocated with the
+ * sizes documented on wg_train_weights) from params[i] = device pointer of canonical parameter i.  Enqueue-only. */
+int wg_train_prepare(wg_handle* h, const void* const* params, int32_t weight_normed, const wg_train_weights* out, void* aux,
+                     size_t aux_bytes, void* stream);
+/* From the packed gradients that wg_train_backward left in *grads to one gradient per parameter: flat[offset_i ..
+ * offset_i + numel_i) with offset_i = sum of the numel of the canonical parameters before i.  The 1x1 weights get the
+ * W.z term only (the logdet term, model.py:63, is the caller's).  Enqueue-only. */
+int wg_train_param_grads(wg_handle* h, const void* const* params, int32_t weight_normed, const wg_train_grads* grads, void* aux,
+                         size_t aux_bytes, float* flat, void* stream);
 
 /* Waves per workgroup of the WN-layer kernel for n_channels (the NW of the fragment orders above); 0 = unsupported. */
 int32_t wg_wn_waves(int32_t n_channels);

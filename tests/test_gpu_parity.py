@@ -37,9 +37,10 @@ def gpu_infer(model, mel, z_init, z_early, sigma, dtype=torch.float32):
   return out.float().cpu()
 
 
-@pytest.mark.parametrize("name", ["c64", "c256", "c512"])
+@pytest.mark.parametrize("name", ["tiny", "c64", "c256", "c512"])
 def test_infer_golden_fp32(name):
-  """fp32 I/O against the committed output of the reference itself."""
+  """fp32 I/O against the committed output of the reference itself.  ("tiny": 16 channels -- a width the kernels are not
+  instantiated for, run zero-padded at 64.)"""
   c = Case(name)
   model = build_model(c.hp, c.sd)
   out = gpu_infer(model, c.mel, c.z_init, c.z_early, c.sigma, torch.float32)
@@ -329,12 +330,22 @@ def test_infer_c256_weightnorm_checkpoint_with_nontrivial_g():
   assert err <= RMS_TOL
 
 
-def test_unsupported_config_is_an_error_not_a_fallback():
-  hp = HParams(n_channels=16, n_layers=3, n_flows=4, n_early_every=2)
+@pytest.mark.parametrize("over", [dict(n_channels=640), dict(kernel_size=5), dict(n_layers=11)], ids=["c640", "k5", "l11"])
+def test_unsupported_config_is_an_error_not_a_fallback(over):
+  """Outside the envelope (n_channels <= 512, kernel_size 3, n_layers <= 10) the library says so; nothing else runs."""
+  hp = HParams(n_flows=4, n_early_every=2, **{"n_channels": 64, "n_layers": 3, **over})
   m = WaveGlow(hp).cuda()
   from waveglow_amd._lib import WgError
   with pytest.raises(WgError):
     m.infer(torch.zeros(1, 80, 4, device="cuda"))
+
+
+def test_training_direction_takes_kernel_widths_only():
+  from waveglow_amd._lib import WgError
+  hp = HParams(n_channels=96, n_layers=2, n_flows=2, n_early_every=1, n_early_size=2)
+  m = WaveGlow(hp).cuda().train()
+  with pytest.raises(WgError):
+    m((torch.zeros(1, 80, 4, device="cuda"), torch.zeros(1, 1024, device="cuda")))
 
 
 def test_cpu_tensor_is_an_error_not_a_fallback():
@@ -639,3 +650,37 @@ def test_synthesizer_against_oracle_composition(tmp_path, strength):
   assert err_d <= RMS_TOL
   assert bool(res.was_overamplified) == bool(np.abs(res.wav).max() > 1.0)
   assert res.sampling_rate == 22050 and res.inference_duration_s > 0
+
+
+@pytest.mark.parametrize("over", [dict(n_channels=96, n_layers=3, n_flows=4, n_early_every=2),
+                                  dict(n_channels=384, n_layers=2, n_flows=2, n_early_every=1, n_early_size=2),
+                                  dict(n_channels=30, n_layers=4, n_flows=4, n_early_every=2),
+                                  dict(n_channels=64, n_layers=9, n_flows=2, n_early_every=1, n_early_size=2),
+                                  dict(n_channels=128, n_layers=10, n_flows=2, n_early_every=1, n_early_size=2)],
+                         ids=["c96", "c384", "c30", "l9", "l10"])
+def test_hparam_envelope_channels_and_layers(over):
+  """The reference takes any even n_channels and any n_layers (model.py:75-113, hparams.py:19-31).  Widths between the
+  instantiated ones run zero-padded (exact); 9 and 10 layers (dilations 256, 512) need 8 / 16 guard frames per utterance
+  instead of 4.  infer and the no-grad forward against the CPU oracle, two utterances long enough for the largest
+  dilation to reach real samples on both sides."""
+  from oracle import torch_oracle as O
+  hp = HParams(**over)
+  sd = synthetic.make_state_dict(hp, seed=17)
+  B, T, sigma = 2, 40, 0.8
+  mel = synthetic.make_mel(B, T, seed=9)
+  z_init, z_early = synthetic.make_noise(hp, B, 32 * T, seed=5)
+  model = build_model(hp, sd)
+  out = gpu_infer(model, mel, z_init, z_early, sigma)
+  with torch.no_grad():
+    ref = O.infer_ref(sd, mel, z_init, z_early, sigma, oracle_cfg_from_hp(hp))
+  err = rms(out - ref)
+  print(f"{over}: infer rms err {err:.3e} (signal rms {rms(ref):.3f})")
+  assert err <= RMS_TOL
+  g = torch.Generator().manual_seed(3)
+  wav = torch.rand(B, 256 * T - 160, generator=g) * 0.6 - 0.3
+  with torch.no_grad():
+    z, log_s, log_det = model((mel.cuda(), wav.cuda()))
+    z_ref, ls_ref, ld_ref = O.forward_ref(sd, mel, wav, oracle_cfg_from_hp(hp))
+  assert rms(z.cpu() - z_ref) <= 2e-3 * max(1.0, rms(z_ref))
+  for a, b in zip(log_s, ls_ref):
+    assert rms(a.cpu() - b) <= 2e-3

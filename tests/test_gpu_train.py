@@ -416,22 +416,29 @@ def test_custom_grad_scale_and_finite_check(monkeypatch):
     WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None).backward()
 
 
-@pytest.mark.parametrize("channels", [64, 256])
-def test_pack_kernel_matches_documented_fragment_orders(channels):
-  """wg_train_pack (one pass per tensor on the device) against the same layouts written as torch index arithmetic
-  (waveglow_amd/train.py: wn_forward_fragments, plain_fragments, to_fragments -- pinned element by element to the header's
-  index maps in tests/test_host_cpu.py): bit-identical fp16 tensors."""
+@pytest.mark.parametrize("channels,wn", [(64, False), (256, False), (64, True), (256, True)])
+def test_prepare_matches_torch_packing(channels, wn):
+  """wg_train_prepare (the library reads the module's own parameter tensors: weight norm, W_end x W_skip fold, permutations,
+  gate pre-scale, fragment orders -- train_prep.hip, pack_kernel) against the same computation written as torch ops
+  (waveglow_amd/train.py: pack_weights, wn_forward_fragments, plain_fragments, to_fragments -- pinned element by element to
+  the header's index maps in tests/test_host_cpu.py).  Dense weights (after remove_weightnorm): every tensor that is pure
+  data movement is bit-identical; with weight norm (and for the fold) the fp32 summation order differs from torch's, so
+  fp16 values may differ in the last place."""
   from waveglow_amd import train as T
   hp = HParams(n_channels=channels, n_layers=3, n_flows=2, n_early_every=1, n_early_size=2)
   sd = synthetic.to_weightnorm_form(synthetic.make_state_dict(hp, seed=21))
   model = WaveGlow(hp)
   model.load_state_dict(sd)
+  if not wn:
+    model = WaveGlow.remove_weightnorm(model)
   model = model.to("cuda:0").train()
   eng = model._get_engine(torch.device("cuda:0"), need_weights=False)
   NW = int(eng.lib.wg_wn_waves(channels))
   with torch.no_grad():
     packed = [t.detach() for t in T.pack_weights(model)]
-    w = T._Weights(model, packed, model.flow_channels(), NW, eng, torch.cuda.current_stream().cuda_stream)
+    names, tensors, is_wn = T.canonical_params(model, eng)
+    assert is_wn == wn and len(tensors) == len(list(model.parameters()))
+    w = T._Weights(model, tensors, wn, model.flow_channels(), eng, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     Cc, M8 = channels, hp.n_mel_channels * 8
     pm = T._perms(Cc, M8, packed[0].device)
@@ -450,5 +457,39 @@ def test_pack_kernel_matches_documented_fragment_orders(channels):
     for name, t in want.items():
       got = getattr(w, name)
       assert got.numel() == t.numel(), name
-      assert torch.equal(got.view(-1).view(torch.int16), t.reshape(-1).view(torch.int16)), name
-    assert torch.equal(w.b1, b1s)
+      if not wn and name not in ("es", "wat"):
+        assert torch.equal(got.view(-1).view(torch.int16), t.reshape(-1).view(torch.int16)), name
+      else:
+        g32, t32 = got.view(-1).float(), t.reshape(-1).float()
+        if name == "es":      # [FL, s, l4, 16 rows, 8]: rows 0-7 the hi fp16 half, 8-15 the lo half -- their SUM is the value
+          g32, t32 = [x.view(FL, Cc // 32, 4, 2, 8, 8).sum(3).reshape(-1) for x in (g32, t32)]
+        tol = 1.5e-3 * t32.abs() + 1e-6
+        assert bool(((g32 - t32).abs() <= tol).all()), (name, float((g32 - t32).abs().max()))
+    assert torch.allclose(w.b1, b1s, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(w.b2, packed[3], rtol=1e-6, atol=1e-7)
+    assert torch.equal(w.bup, packed[6].index_select(0, pm.m8))
+    start5, out_init, w1x1 = packed[7].index_select(2, pm.c), packed[8], packed[9]
+    for k, c in enumerate(model.flow_channels()):
+      assert torch.allclose(w.wstart[k].view(Cc, c // 2), start5[k, :c // 2].transpose(0, 1), rtol=2e-6, atol=1e-7), k
+      assert torch.equal(w.bstart[k], start5[k, 4]), k
+      assert torch.allclose(w.out_init[k], out_init[k], rtol=1e-5, atol=1e-6), k
+      assert torch.equal(w.w1x1[k].view(c, c), w1x1[k, :c, :c]), k
+
+
+def test_training_on_dense_weights_after_remove_weightnorm():
+  """The training direction also takes a model whose weight norm has been removed (plain ``weight`` parameters): the
+  gradients are then the dense weights' own (oracle: the same state dict in dense form)."""
+  from oracle import torch_oracle as O
+  over = dict(n_channels=64, n_layers=3, n_flows=4, n_early_every=2)
+  hp, sd, mel, wav = _setup(over, 2, 6, 2)
+  model = WaveGlow.remove_weightnorm(WaveGlow(hp))
+  dense = synthetic.make_state_dict(hp, seed=2)
+  model.load_state_dict(dense)
+  model = model.to("cuda:0").train()
+  loss = WaveGlowLoss(1.0)(model((mel.cuda(), wav.cuda())), None)
+  loss.backward()
+  torch.cuda.synchronize()
+  assert bool(model.grad_finite)
+  loss_ref, g_ref = O.grads_ref(dense, mel, wav, oracle_cfg_from_hp(hp), 1.0)
+  assert abs(float(loss.detach()) - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+  _check({n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}, g_ref, "dense")

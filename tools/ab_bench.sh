@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 FLAGS=$1; shift
 LIB=$ROOT/gpurun_out/lib_variantB.so
 mkdir -p $ROOT/gpurun_out
-(cd $ROOT/waveglow_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value $FLAGS -o $LIB kernels.hip stft.hip train.hip api.cpp stft_api.cpp train_api.cpp) || exit 1
+(cd $ROOT/waveglow_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value $FLAGS -o $LIB kernels.hip stft.hip train.hip train_prep.hip api.cpp stft_api.cpp train_api.cpp) || exit 1
 for round in 1 2 3; do
   for v in A B; do
     if [ $v = A ]; then unset WAVEGLOW_AMD_LIB; else export WAVEGLOW_AMD_LIB=$LIB; fi

@@ -5,7 +5,7 @@ mkdir -p $ROOT/gpurun_out
 i=0
 for F in "$@"; do
   i=$((i+1))
-  (cd $ROOT/waveglow_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value $F -o $ROOT/gpurun_out/lib_v$i.so kernels.hip stft.hip train.hip api.cpp stft_api.cpp train_api.cpp) || exit 1
+  (cd $ROOT/waveglow_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value $F -o $ROOT/gpurun_out/lib_v$i.so kernels.hip stft.hip train.hip train_prep.hip api.cpp stft_api.cpp train_api.cpp) || exit 1
 done
 for round in 1 2 3; do
   for v in $(seq 0 $i); do

@@ -19,7 +19,7 @@ if os.environ.get("WG_STAMP_LIB"):          # prebuilt with tools/build_variant.
   lib = os.path.abspath(os.environ["WG_STAMP_LIB"])
 else:
   subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-                  "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "stft.hip", "train.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"], cwd=csrc, check=True)
+                  "-DWG_STAMPS"] + extra + ["-o", lib, "kernels.hip", "stft.hip", "train.hip", "train_prep.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"], cwd=csrc, check=True)
 os.environ["WAVEGLOW_AMD_LIB"] = lib
 
 import torch  # noqa: E402

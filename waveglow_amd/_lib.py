@@ -67,10 +67,20 @@ SIGNATURES = {
                            C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_loss": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
                         C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+  "wg_loss_dev": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
+                            C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
   "wg_macs_per_group_step": (C.c_double, [C.c_void_p]),
   "wg_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
   "wg_wn_waves": (C.c_int32, [C.c_int32]),
   "wg_train_pack": (C.c_int, [C.c_void_p, C.POINTER(WgTrainPlain), C.POINTER(WgTrainWeights), C.c_void_p]),
+  "wg_train_param_count": (C.c_int32, [C.c_void_p, C.c_int32]),
+  "wg_train_param_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
+  "wg_train_param_numel": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+  "wg_train_prepare_bytes": (C.c_size_t, [C.c_void_p]),
+  "wg_train_prepare": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(WgTrainWeights), C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+  "wg_train_param_grads": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(WgTrainGrads), C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.c_void_p]),
   "wg_train_forward": (C.c_int, [C.c_void_p, C.POINTER(WgTrainWeights), C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),

@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libwaveglow_amd.so")
-SOURCES = ["kernels.hip", "stft.hip", "train.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"]
+SOURCES = ["kernels.hip", "stft.hip", "train.hip", "train_prep.hip", "api.cpp", "stft_api.cpp", "train_api.cpp"]
 HEADERS = ["wg_common.h", "wg_train.h", os.path.join("..", "..", "include", "waveglow_amd.h")]
 
 

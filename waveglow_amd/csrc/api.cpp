@@ -154,7 +154,11 @@ RowGeom make_geom(const wg_config& c, int B, int L, int T) {
   g.B = B;
   g.L = L;
   g.F = (L + kPhases - 1) / kPhases;
-  g.Gf = 4;                                  // (phase + dilation) >> 5 <= 4 for dilation <= 128 (n_layers <= 8)
+  // guard frames: a dilated tap reaches (phase + dilation) >> 5 frames past an utterance's ends; dilation <= 2^(n_layers-1)
+  // (model.py:97): 4 frames up to 8 layers, 8 / 16 for 9 / 10 layers
+  const int max_dil = 1 << (c.n_layers - 1);
+  g.Gf = (kPhases - 1 + max_dil) / kPhases;
+  if (g.Gf < 4) g.Gf = 4;
   g.Fp = g.Gf + g.F + g.Gf;
   g.Rp = (B * g.Fp + 127) / 128 * 128;
   g.R = kPhases * g.Rp + 2 * kRowPad;
@@ -294,7 +298,7 @@ int wg_create(const wg_config* cfg, int device_id, wg_handle** out) {
   if (c.kernel_size != 3) return fail(WG_ERR_INVALID, "kernel_size=%d unsupported (only 3)", c.kernel_size);
   if (c.n_channels != 64 && c.n_channels != 128 && c.n_channels != 256 && c.n_channels != 512)
     return fail(WG_ERR_INVALID, "n_channels=%d unsupported (64, 128, 256, 512)", c.n_channels);
-  if (c.n_layers < 1 || c.n_layers > 8) return fail(WG_ERR_INVALID, "n_layers=%d unsupported (1..8)", c.n_layers);
+  if (c.n_layers < 1 || c.n_layers > 10) return fail(WG_ERR_INVALID, "n_layers=%d unsupported (1..10)", c.n_layers);
   if (c.upsample_kernel != 1024 || c.upsample_stride != 256)
     return fail(WG_ERR_INVALID, "upsample geometry %d/%d unsupported (1024/256)", c.upsample_kernel, c.upsample_stride);
   if (c.n_mel_channels < 16 || c.n_mel_channels > 80 || c.n_mel_channels % 16 != 0)
@@ -892,9 +896,10 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
   return WG_OK;
 }
 
-int wg_loss(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
-            const float* log_det_W, float sigma, float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!z || !log_s || !log_s_elems || !log_det_W || !loss_out || !workspace) return fail(WG_ERR_INVALID, "null buffer");
+static int loss_impl(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
+                     const float* log_det_host, const float* log_det_dev, float sigma, float* loss_out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (!z || !log_s || !log_s_elems || (!log_det_host && !log_det_dev) || !loss_out || !workspace) return fail(WG_ERR_INVALID, "null buffer");
   if (z_elems < 1 || n_flows < 1 || !(sigma > 0.f)) return fail(WG_ERR_INVALID, "bad sizes/sigma");
   if (workspace_bytes < 16) return fail(WG_ERR_WORKSPACE, "workspace %zu < required 16", workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
@@ -905,10 +910,20 @@ int wg_loss(const float* z, int64_t z_elems, const float* const* log_s, const in
   for (int k = 0; k < n_flows; ++k) {
     if (!log_s[k] || log_s_elems[k] < 1) return fail(WG_ERR_INVALID, "bad log_s[%d]", k);
     HIP_TRY(launch_reduce_sum(log_s[k], (size_t)log_s_elems[k], 0, acc + 1, s));          // sum log_s    train.py:36-40
-    log_det_total += (double)log_det_W[k];                                                // train.py:37,41
+    if (log_det_host) log_det_total += (double)log_det_host[k];                           // train.py:37,41
   }
-  HIP_TRY(launch_loss_final(acc, log_det_total, sigma, (double)z_elems, loss_out, s));    // train.py:43-44
+  HIP_TRY(launch_loss_final(acc, log_det_total, log_det_dev, log_det_dev ? n_flows : 0, sigma, (double)z_elems, loss_out, s));   // train.py:43-44
   return WG_OK;
+}
+
+int wg_loss(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
+            const float* log_det_W, float sigma, float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return loss_impl(z, z_elems, log_s, log_s_elems, n_flows, log_det_W, nullptr, sigma, loss_out, workspace, workspace_bytes, stream);
+}
+
+int wg_loss_dev(const float* z, int64_t z_elems, const float* const* log_s, const int64_t* log_s_elems, int32_t n_flows,
+                const float* log_det_W_dev, float sigma, float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return loss_impl(z, z_elems, log_s, log_s_elems, n_flows, nullptr, log_det_W_dev, sigma, loss_out, workspace, workspace_bytes, stream);
 }
 
 double wg_macs_per_group_step(const wg_handle* h) {

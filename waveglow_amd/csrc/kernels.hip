@@ -1631,7 +1631,9 @@ __global__ void __launch_bounds__(256) reduce_sum_kernel(const float* __restrict
   if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ void loss_final_kernel(const double* acc, double log_det_total, float sigma, double denom, float* out) {
+__global__ void loss_final_kernel(const double* acc, double log_det_total, const float* log_det_dev, int n_dev, float sigma,
+                                  double denom, float* out) {
+  for (int k = 0; k < n_dev; ++k) log_det_total += (double)log_det_dev[k];     // same order as the host sum (train.py:37,41)
   *out = (float)((acc[0] / (2.0 * (double)sigma * (double)sigma) - acc[1] - log_det_total) / denom);
 }
 
@@ -1643,8 +1645,9 @@ hipError_t launch_reduce_sum(const float* x, size_t n, int square, double* acc, 
   else hipLaunchKernelGGL(reduce_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, n, acc);
   return hipGetLastError();
 }
-hipError_t launch_loss_final(const double* acc, double log_det_total, float sigma, double denom, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, s, acc, log_det_total, sigma, denom, out);
+hipError_t launch_loss_final(const double* acc, double log_det_total, const float* log_det_dev, int n_dev, float sigma, double denom,
+                             float* out, hipStream_t s) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, s, acc, log_det_total, log_det_dev, n_dev, sigma, denom, out);
   return hipGetLastError();
 }
 

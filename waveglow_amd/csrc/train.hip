@@ -816,27 +816,59 @@ hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int 
 // =============================================================================================
 namespace {
 __device__ __forceinline__ int nat0_of(int p0) { return 16 * ((p0 >> 3) & 1) + 4 * (p0 >> 4); }   // p0 in {0, 8, 16, 24}
-__device__ __forceinline__ half8 cvt8(const float4 lo, const float4 hi, float sc) {
-  half8 o;
-  o[0] = (_Float16)(lo.x * sc); o[1] = (_Float16)(lo.y * sc); o[2] = (_Float16)(lo.z * sc); o[3] = (_Float16)(lo.w * sc);
-  o[4] = (_Float16)(hi.x * sc); o[5] = (_Float16)(hi.y * sc); o[6] = (_Float16)(hi.z * sc); o[7] = (_Float16)(hi.w * sc);
-  return o;
-}
-// 8 K positions of one row that are contiguous runs in memory: row[n0 .. n0+3], row[n0+8 .. n0+11]
-__device__ __forceinline__ half8 row_runs(const float* row, int n0, float sc) {
-  return cvt8(*(const float4*)(row + n0), *(const float4*)(row + n0 + 8), sc);
-}
-// 8 K positions that are 8 ROWS of one column: rows r0 .. r0+3 and r0+8 .. r0+11 (row stride ld)
-__device__ __forceinline__ half8 col_runs(const float* col, int r0, size_t ld) {
-  half8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (_Float16)col[(size_t)(r0 + (j & 3) + 2 * (j & 4)) * ld];
-  return o;
-}
 }  // namespace
+
+// Element accessors of the stacked natural-order matrices.  native = 0: they exist in memory (wg_train_plain).  native = 1
+// (wg_train_prepare): read from the module's own tensors with the weight-norm row scale applied on the fly --
+//   W1[fl][m][n]: n < 3C: in_layers[fl].weight[m][c = n % C][tap = n / C] (native [2C][C][3]); else cond_layer row
+//   (fl % nl) * 2C + m, column n - 3C;   W2[fl][r][c]: res rows of res_skip_layers[fl] (zero in a flow's last layer).
+// An fp32 product that is about to be rounded to fp16 must be ROUNDED TO fp32 FIRST (what torch's weight norm followed by
+// .half() does): left alone hipcc may fuse multiply and conversion into one v_fma_mix* with a single rounding, which
+// differs from the two-step result in the last place of ~3 elements per 100 000.
+__device__ __forceinline__ float f32_rounded(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+struct PackSrc {
+  const PackArgs& a;
+  __device__ __forceinline__ float w1(int fl, int m, int n) const {
+    const int C = a.C;
+    if (!a.native) return a.w1[((size_t)fl * 2 * C + m) * (3 * C + a.M8) + n];
+    const PrepArgs& p = a.prep;
+    if (n < 3 * C) {
+      const int tap = n / C, c = n - tap * C;
+      return f32_rounded(((const float*)p.tab[prep_slot(p, SEC_IN_V, fl)])[((size_t)m * C + c) * 3 + tap] * p.s_in[(size_t)fl * 2 * C + m]);
+    }
+    const int k = fl / p.nl, row = (fl % p.nl) * 2 * C + m;
+    return f32_rounded(((const float*)p.tab[prep_slot(p, SEC_CO_V, k)])[(size_t)row * a.M8 + (n - 3 * C)] * p.s_co[(size_t)k * 2 * C * p.nl + row]);
+  }
+  __device__ __forceinline__ float w2(int fl, int r, int c) const {
+    const int C = a.C;
+    if (!a.native) return a.w2[((size_t)fl * C + r) * C + c];
+    const PrepArgs& p = a.prep;
+    if (fl % p.nl == p.nl - 1) return 0.0f;
+    return f32_rounded(((const float*)p.tab[prep_slot(p, SEC_RS_V, fl)])[(size_t)r * C + c] * p.s_rs[(size_t)fl * 2 * C + r]);
+  }
+  // Wup[p][row = 8 o + g][col = 128 j + i] = upsample.weight[i][o][256 j + 8 p + g], zero for i >= M
+  __device__ __forceinline__ float wup(int ph, int row, int col) const {
+    if (!a.native) return a.wup[((size_t)ph * a.M8 + row) * 512 + col];
+    const int M = a.M8 / 8, j = col >> 7, i = col & 127, o = row >> 3, g = row & 7;
+    if (i >= M) return 0.0f;
+    return ((const float*)a.prep.tab[prep_slot(a.prep, SEC_UP_W, 0)])[((size_t)i * M + o) * 1024 + 256 * j + 8 * ph + g];
+  }
+};
 
 __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
   const int C = a.C, M8 = a.M8, NW = a.NW, MB = C / (32 * NW), K1 = 3 * C + M8;
+  const PackSrc S{a};
+  // 8 K positions of a row that are two runs of four natural columns n0..n0+3, n0+8..n0+11
+  auto w1_row_runs = [&](int fl, int m, int n0, float sc) -> half8 {
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)f32_rounded(S.w1(fl, m, n0 + (j & 3) + 2 * (j & 4)) * sc);
+    return o;
+  };
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < a.n_pieces; q += (size_t)gridDim.x * 256) {
     half8 o;
     _Float16* dst = a.dst + q * 8;
@@ -853,7 +885,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
       const int gate = mtq / MB, mb = mtq - gate * MB;
       const int m = gate * C + 32 * (w * MB + mb) + r;
       const int n0 = 64 * ks + 32 * u1 + nat0_of(16 * k2 + 8 * hh);
-      o = row_runs(a.w1 + ((size_t)fl * 2 * C + m) * K1, n0, gate ? -1.4426950408889634f : 2.8853900817779268f);
+      o = w1_row_runs(fl, m, n0, gate ? -1.4426950408889634f : 2.8853900817779268f);
       const int n_tap = 3 * C / 64;
       if (ks < n_tap) dst = a.dst + (((size_t)fl * n_tap + ks) * per_ks + e) * 8;
       else dst = a.dst2 + (((size_t)fl * (K1 / 64 - n_tap) + (ks - n_tap)) * per_ks + e) * 8;
@@ -865,7 +897,8 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
       e /= (C / 16);
       const int blk = (int)(e % (NW * MB)), fl = (int)(e / (NW * MB));
       const int n0 = 32 * (k16 >> 1) + nat0_of(16 * (k16 & 1) + 8 * hh);
-      o = row_runs(a.w2 + ((size_t)fl * C + 32 * blk + r) * C, n0, 1.0f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (_Float16)S.w2(fl, 32 * blk + r, n0 + (j & 3) + 2 * (j & 4));
     } else if (a.kind == PACK_ES) {
       // [FL][s][l4][row][8]: hi (row < 8) / lo (row >= 8) fp16 half of Wes[row & 7][position 32 s + 8 l4]
       const int row = q & 15, l4 = (q >> 4) & 3;
@@ -894,10 +927,14 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
       if (a.kind == PACK_WBT) {
         // Mat = W_in[:, :, tap]^T: K = tap * 2C + (position of the d pre row)
         const int tap = k0 / (2 * C), q0 = k0 - tap * 2 * C;
-        o = col_runs(a.w1 + (size_t)fl * 2 * C * K1 + tap * C + m, q0 + nat0_of(p0), (size_t)K1);
+        const int r0 = q0 + nat0_of(p0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)S.w1(fl, r0 + (j & 3) + 2 * (j & 4), tap * C + m);
       } else if (k0 < C) {
         // Mat = [ W_res^T | ... ]: K = position of the d x row
-        o = col_runs(a.w2 + (size_t)fl * C * C + m, k0 + nat0_of(p0), (size_t)C);
+        const int r0 = k0 + nat0_of(p0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)S.w2(fl, r0 + (j & 3) + 2 * (j & 4), m);
       } else {
         // ... | (W_end W_skip)^T, 8 channels, padded to 64 ]
 #pragma unroll
@@ -914,7 +951,9 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
       const size_t t = e / (M8 / 32);
       const size_t kc = 64 * t + 32 * h + 8 * s_;
       const int fl = (int)(kc / (2 * C)), q0 = (int)(kc - (size_t)fl * 2 * C);
-      o = col_runs(a.w1 + (size_t)fl * 2 * C * K1 + 3 * C + 32 * b + r, (q0 & ~31) + nat0_of(q0 & 31), (size_t)K1);
+      const int r0 = (q0 & ~31) + nat0_of(q0 & 31);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (_Float16)S.w1(fl, r0 + (j & 3) + 2 * (j & 4), 3 * C + 32 * b + r);
     } else {
       // PACK_WUP [p][t][b][s][h][r][8] = Wup[p][32 b + r][64 t + 32 h + 8 s + j]   (rows natural: pos(chan_to_pos(r)) = r)
       const int r = q & 31, h = (q >> 5) & 1, s_ = (q >> 6) & 3;
@@ -922,8 +961,8 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
       const int b = (int)(e % (M8 / 32));
       e /= (M8 / 32);
       const int t = (int)(e % 8), p = (int)(e / 8);
-      const float* src = a.wup + ((size_t)p * M8 + 32 * b + r) * 512 + 64 * t + 32 * h + 8 * s_;
-      o = cvt8(*(const float4*)src, *(const float4*)(src + 4), 1.0f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (_Float16)S.wup(p, 32 * b + r, 64 * t + 32 * h + 8 * s_ + j);
     }
     *(half8*)dst = o;
   }

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/waveglow_amd.h"
 #include "wg_train.h"
@@ -528,10 +529,11 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   // n for launch n itself (l_done).
   int n_layer = 0;
   // (marks are waited on one or two flows / launches after their record: events of their own, wg_internal_mark_event,
-  //  slots 0-7 = w_done[layer], 8-9 = w_flow[parity], 10-11 = l_done[set], 12-13 = r_done[set]; a null entry = not recorded
+  //  slots 0-9 = w_done[layer], 10-11 = w_flow[parity], 12-13 = l_done[set], 14-15 = r_done[set]; a null entry = not recorded
   //  in this call, nothing to wait for)
-  hipEvent_t w_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, w_flow[2] = {nullptr, nullptr};
-  hipEvent_t l_done[2] = {nullptr, nullptr}, r_done[2] = {nullptr, nullptr};
+  hipEvent_t w_done[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t w_flow[2] = {nullptr, nullptr}, l_done[2] = {nullptr, nullptr}, r_done[2] = {nullptr, nullptr};
+  if (nl > 10) return wg_set_error(WG_ERR_INVALID, "more than 10 layers");
   auto mark = [&](hipStream_t st, hipEvent_t& e, int slot) -> hipError_t {
     e = nullptr;
     if (x.serial) return hipSuccess;
@@ -634,7 +636,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         jb[1].extra_bias_out = w.extb[set];
         TR_ORDER(wait_for(sW, r_done[set]));          // the reduction of the launch before last has read this slab set
         TR_PROF(sW, 6, TR_TRY(launch_wgrad(jb, 2, g, n_slabs, sW)));
-        TR_ORDER(mark(sW, l_done[set], 10 + set));
+        TR_ORDER(mark(sW, l_done[set], 12 + set));
         // ---- reduction of everything this launch left behind, in NATURAL channel order (SlabSeg: perm bit 0 = rows are
         // channels, bit 1 = columns are)
         SlabSeg seg[kMaxSlabSegs];
@@ -660,7 +662,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         if (i == 0) add_flat(w.extb[set], 16, 8, gr->dout_init[k], 0, 0);
         TR_ORDER(wait_for(sR, l_done[set]));
         TR_TRY(launch_slab_reduce_multi(seg, n_seg, sR));
-        TR_ORDER(mark(sR, r_done[set], 12 + set));
+        TR_ORDER(mark(sR, r_done[set], 14 + set));
         TR_ORDER(mark(sW, w_done[i], i));
       }
       {
@@ -687,7 +689,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         gx = gxi;
       }
     }
-    TR_ORDER(mark(sW, w_flow[k & 1], 8 + (k & 1)));
+    TR_ORDER(mark(sW, w_flow[k & 1], 10 + (k & 1)));
     TR_ORDER(order_after(h, sB, s));
     {
       StartWgradArgs a;
@@ -758,6 +760,216 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
   }
   TR_ORDER(order_after(h, sW, s));        // every gradient of the call is final on the caller's stream
   TR_ORDER(order_after(h, sR, s));
+  return WG_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Training plumbing on the device (train_prep.hip): parameters in their own tensors -> wg_train_weights, packed gradients ->
+// one gradient per parameter.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct ParamDesc { int sec, idx; long long numel; std::string name; };
+
+// canonical parameter list: section-major (wg_train.h: PrepSec), g sections only for weight-normed modules
+std::vector<ParamDesc> param_list(const wg_config& c, const int* ck, bool wn) {
+  std::vector<ParamDesc> out;
+  const int C = c.n_channels, nl = c.n_layers, nf = c.n_flows, M = c.n_mel_channels, M8 = 8 * M, FL = nf * nl;
+  auto wname = [&](const std::string& mod, int which) {     // 0: v / dense weight, 1: g
+    if (!wn) return mod + ".weight";
+    return mod + (which ? ".parametrizations.weight.original0" : ".parametrizations.weight.original1");
+  };
+  for (int sec = 0; sec <= SEC_UP_B; ++sec) {
+    const bool is_g = sec == SEC_IN_G || sec == SEC_RS_G || sec == SEC_CO_G || sec == SEC_ST_G;
+    if (is_g && !wn) continue;
+    const int n = prep_sec_len(FL, nf, sec);
+    for (int q = 0; q < n; ++q) {
+      ParamDesc d;
+      d.sec = sec;
+      d.idx = q;
+      const int k = sec <= SEC_RS_B ? q / nl : q, i = sec <= SEC_RS_B ? q % nl : 0, h = ck[k < nf ? k : 0] / 2;
+      const std::string wnp = "WN." + std::to_string(k) + ".";
+      const std::string in = wnp + "in_layers." + std::to_string(i), rs = wnp + "res_skip_layers." + std::to_string(i);
+      const long long rs_rows = i < nl - 1 ? 2 * C : C;
+      switch (sec) {
+        case SEC_IN_V: d.name = wname(in, 0); d.numel = (long long)2 * C * C * 3; break;
+        case SEC_IN_G: d.name = wname(in, 1); d.numel = 2 * C; break;
+        case SEC_IN_B: d.name = in + ".bias"; d.numel = 2 * C; break;
+        case SEC_RS_V: d.name = wname(rs, 0); d.numel = rs_rows * C; break;
+        case SEC_RS_G: d.name = wname(rs, 1); d.numel = rs_rows; break;
+        case SEC_RS_B: d.name = rs + ".bias"; d.numel = rs_rows; break;
+        case SEC_CO_V: d.name = wname(wnp + "cond_layer", 0); d.numel = (long long)2 * C * nl * M8; break;
+        case SEC_CO_G: d.name = wname(wnp + "cond_layer", 1); d.numel = (long long)2 * C * nl; break;
+        case SEC_CO_B: d.name = wnp + "cond_layer.bias"; d.numel = (long long)2 * C * nl; break;
+        case SEC_ST_V: d.name = wname(wnp + "start", 0); d.numel = (long long)C * h; break;
+        case SEC_ST_G: d.name = wname(wnp + "start", 1); d.numel = C; break;
+        case SEC_ST_B: d.name = wnp + "start.bias"; d.numel = C; break;
+        case SEC_EN_W: d.name = wnp + "end.weight"; d.numel = (long long)2 * h * C; break;
+        case SEC_EN_B: d.name = wnp + "end.bias"; d.numel = 2 * h; break;
+        case SEC_CV_W: d.name = "convinv." + std::to_string(k) + ".conv.weight"; d.numel = (long long)ck[k] * ck[k]; break;
+        case SEC_UP_W: d.name = "upsample.weight"; d.numel = (long long)M * M * c.upsample_kernel; break;
+        default: d.name = "upsample.bias"; d.numel = M; break;
+      }
+      out.push_back(d);
+    }
+  }
+  return out;
+}
+
+struct PrepLayout {
+  size_t tab, goff, s_in, s_co, s_rs, s_st, wend8, bsum, wes, bytes;
+  int n_slots, n_scale[4];
+};
+PrepLayout prep_layout(const wg_config& c) {
+  PrepLayout L;
+  const int C = c.n_channels, nl = c.n_layers, nf = c.n_flows, FL = nf * nl;
+  L.n_slots = prep_slot_n(FL, nf, SEC_COUNT, 0);
+  L.n_scale[0] = FL * 2 * C; L.n_scale[1] = nf * 2 * C * nl; L.n_scale[2] = FL * 2 * C; L.n_scale[3] = nf * C;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
+  L.tab = take((size_t)L.n_slots * sizeof(void*));
+  L.goff = take((size_t)L.n_slots * sizeof(long long));
+  L.s_in = take((size_t)2 * L.n_scale[0] * 4);
+  L.s_co = take((size_t)2 * L.n_scale[1] * 4);
+  L.s_rs = take((size_t)2 * L.n_scale[2] * 4);
+  L.s_st = take((size_t)2 * L.n_scale[3] * 4);
+  L.wend8 = take((size_t)nf * 8 * C * 4);
+  L.bsum = take((size_t)nf * C * 4);
+  L.wes = take((size_t)FL * 8 * C * 4);
+  L.bytes = off;
+  return L;
+}
+
+// fills the argument block and uploads the pointer table (parameters + the per-flow buffers of `wt` / `gr`)
+int prep_args(wg_handle* h, const void* const* params, int weight_normed, const wg_train_weights* wt, const wg_train_grads* gr,
+              void* aux, size_t aux_bytes, float* flat, hipStream_t s, PrepArgs& a) {
+  if (!h || !params || !aux) return wg_set_error(WG_ERR_INVALID, "null argument");
+  const wg_config& c = *wg_internal_config(h);
+  const int* ck = wg_internal_flow_channels(h);
+  if (c.n_flows > kPrepMaxFlows) return wg_set_error(WG_ERR_INVALID, "more than 32 flows are not supported by the training direction");
+  if (c.upsample_kernel != 1024) return wg_set_error(WG_ERR_INVALID, "upsample kernel must be 1024");
+  const PrepLayout L = prep_layout(c);
+  if (aux_bytes < L.bytes) return wg_set_error(WG_ERR_WORKSPACE, "wg_train_prepare: aux buffer too small");
+  const int nf = c.n_flows, FL = nf * c.n_layers;
+  std::vector<void*> tab((size_t)L.n_slots, nullptr);
+  std::vector<long long> goff((size_t)L.n_slots, 0);
+  const std::vector<ParamDesc> pl = param_list(c, ck, weight_normed != 0);
+  long long off = 0;
+  for (size_t i = 0; i < pl.size(); ++i) {
+    if (!params[i]) return wg_set_error(WG_ERR_INVALID, ("null parameter pointer: " + pl[i].name).c_str());
+    const int slot = prep_slot_n(FL, nf, pl[i].sec, pl[i].idx);
+    tab[slot] = const_cast<void*>(params[i]);
+    goff[slot] = off;
+    off += pl[i].numel;
+  }
+  for (int k = 0; k < nf; ++k) {
+    if (wt) {
+      tab[prep_slot_n(FL, nf, SEC_O_WSTART, k)] = const_cast<float*>(wt->wstart[k]);
+      tab[prep_slot_n(FL, nf, SEC_O_BSTART, k)] = const_cast<float*>(wt->bstart[k]);
+      tab[prep_slot_n(FL, nf, SEC_O_OINIT, k)] = const_cast<float*>(wt->out_init[k]);
+      tab[prep_slot_n(FL, nf, SEC_O_W1X1, k)] = const_cast<float*>(wt->w1x1[k]);
+    }
+    if (gr) {
+      tab[prep_slot_n(FL, nf, SEC_G_DSTART, k)] = gr->dstart[k];
+      tab[prep_slot_n(FL, nf, SEC_G_DOINIT, k)] = gr->dout_init[k];
+      tab[prep_slot_n(FL, nf, SEC_G_DW1X1, k)] = gr->dw1x1[k];
+    }
+  }
+  char* base = (char*)aux;
+  TR_TRY(hipMemcpyAsync(base + L.tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+  TR_TRY(hipMemcpyAsync(base + L.goff, goff.data(), goff.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  memset(&a, 0, sizeof a);
+  a.tab = (void* const*)(base + L.tab);
+  a.goff = (const long long*)(base + L.goff);
+  a.flat = flat;
+  a.s_in = (float*)(base + L.s_in); a.s_co = (float*)(base + L.s_co); a.s_rs = (float*)(base + L.s_rs); a.s_st = (float*)(base + L.s_st);
+  a.wend8 = (float*)(base + L.wend8); a.bsum = (float*)(base + L.bsum); a.wes = (float*)(base + L.wes);
+  a.C = c.n_channels; a.M8 = c.n_mel_channels * 8; a.nl = c.n_layers; a.nf = nf; a.FL = FL;
+  for (int k = 0; k < nf; ++k) { a.ck[k] = ck[k]; a.hk[k] = ck[k] / 2; }
+  for (int q = 0; q < 4; ++q) a.n_scale[q] = L.n_scale[q];
+  if (wt) { a.b1 = const_cast<float*>(wt->b1); a.b2 = const_cast<float*>(wt->b2); a.bup = const_cast<float*>(wt->bup); }
+  if (gr) {
+    a.dw1 = gr->dw1; a.db1 = gr->db1; a.dw2 = gr->dw2; a.db2 = gr->db2; a.dwes = gr->dwes; a.dwup = gr->dwup; a.dbup = gr->dbup;
+    a.layer_stride = gr->layer_stride; a.flow_stride = gr->flow_stride;
+  }
+  return WG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t wg_train_param_count(const wg_handle* h, int32_t weight_normed) {
+  if (!h) return 0;
+  return (int32_t)param_list(*wg_internal_config(h), wg_internal_flow_channels(h), weight_normed != 0).size();
+}
+
+const char* wg_train_param_name(const wg_handle* h, int32_t weight_normed, int32_t i) {
+  static thread_local std::string name;
+  if (!h) return "";
+  const std::vector<ParamDesc> pl = param_list(*wg_internal_config(h), wg_internal_flow_channels(h), weight_normed != 0);
+  if (i < 0 || (size_t)i >= pl.size()) return "";
+  name = pl[i].name;
+  return name.c_str();
+}
+
+int64_t wg_train_param_numel(const wg_handle* h, int32_t weight_normed, int32_t i) {
+  if (!h) return 0;
+  const std::vector<ParamDesc> pl = param_list(*wg_internal_config(h), wg_internal_flow_channels(h), weight_normed != 0);
+  return (i < 0 || (size_t)i >= pl.size()) ? 0 : pl[i].numel;
+}
+
+size_t wg_train_prepare_bytes(const wg_handle* h) { return h ? prep_layout(*wg_internal_config(h)).bytes : 0; }
+
+int wg_train_prepare(wg_handle* h, const void* const* params, int32_t weight_normed, const wg_train_weights* out, void* aux,
+                     size_t aux_bytes, void* stream) {
+  if (!out) return wg_set_error(WG_ERR_INVALID, "null argument");
+  if (!out->a1 || !out->a1c || !out->b1 || !out->a2 || !out->b2 || !out->es || !out->wat || !out->wbt || !out->wct || !out->wup ||
+      !out->bup || !out->wstart || !out->bstart || !out->out_init || !out->w1x1)
+    return wg_set_error(WG_ERR_INVALID, "wg_train_prepare: wg_train_weights has a null member");
+  hipStream_t s = (hipStream_t)stream;
+  PrepArgs pa;
+  int rc = prep_args(h, params, weight_normed, out, nullptr, aux, aux_bytes, nullptr, s, pa);
+  if (rc) return rc;
+  TR_TRY(launch_prepare(pa, s));
+  const wg_config& c = *wg_internal_config(h);
+  const int C = c.n_channels, M8 = c.n_mel_channels * 8, FL = c.n_flows * c.n_layers, NW = wn_waves(C);
+  if (NW <= 0 || M8 % 64) return wg_set_error(WG_ERR_INVALID, "wg_train_prepare: unsupported channel counts");
+  const size_t K1 = 3 * (size_t)C + M8;
+  PackArgs a;
+  memset(&a, 0, sizeof a);
+  a.C = C; a.M8 = M8; a.FL = FL; a.NW = NW;
+  a.native = 1;
+  a.prep = pa;
+  a.wes = pa.wes;
+  auto run = [&](int kind, const void* dst, const void* dst2, size_t elements) -> hipError_t {
+    a.kind = kind;
+    a.dst = (_Float16*)const_cast<void*>(dst);
+    a.dst2 = (_Float16*)const_cast<void*>(dst2);
+    a.n_pieces = elements / 8;
+    return launch_pack(a, s);
+  };
+  TR_TRY(run(PACK_A1, out->a1, out->a1c, (size_t)FL * 2 * C * K1));
+  TR_TRY(run(PACK_A2, out->a2, nullptr, (size_t)FL * C * C));
+  TR_TRY(run(PACK_ES, out->es, nullptr, (size_t)FL * 16 * C));
+  TR_TRY(run(PACK_WAT, out->wat, nullptr, (size_t)FL * C * (C + 64)));
+  TR_TRY(run(PACK_WBT, out->wbt, nullptr, (size_t)FL * C * 6 * C));
+  TR_TRY(run(PACK_WCT, out->wct, nullptr, (size_t)M8 * FL * 2 * C));
+  TR_TRY(run(PACK_WUP, out->wup, nullptr, (size_t)32 * M8 * 512));
+  return WG_OK;
+}
+
+int wg_train_param_grads(wg_handle* h, const void* const* params, int32_t weight_normed, const wg_train_grads* grads, void* aux,
+                         size_t aux_bytes, float* flat, void* stream) {
+  if (!grads || !flat) return wg_set_error(WG_ERR_INVALID, "null argument");
+  int rc = check_grads(grads, wg_internal_config(h) ? wg_internal_config(h)->n_flows : 0);
+  if (rc) return rc;
+  PrepArgs pa;
+  rc = prep_args(h, params, weight_normed, nullptr, grads, aux, aux_bytes, flat, (hipStream_t)stream, pa);
+  if (rc) return rc;
+  TR_TRY(launch_param_grads(pa, (hipStream_t)stream));
   return WG_OK;
 }
 

@@ -52,7 +52,8 @@ struct RowGeom {
                        // t >= 32 * frames[b] of utterance b are padding: never written, so they read as the zero padding
                        // of the convolutions exactly as in a batch-of-one call.  null: every utterance has L columns.
 };
-constexpr int kRowPad = 8;       // zero slack rows in front of / behind every plane chunk (taps of the first/last tile)
+constexpr int kRowPad = 16;      // zero slack rows in front of / behind every plane chunk (taps of the first / last tile reach up to
+                                 // Gf <= 16 rows past it: the guard rows of a tile read as far outside as its valid rows do)
 constexpr int kPhases = 32;
 
 struct WnLayerArgs {
@@ -152,6 +153,7 @@ int wn_block_n(int C);   // default BN for channel count C
 int wn_waves(int C);     // waves per workgroup for channel count C
 
 hipError_t launch_reduce_sum(const float* x, size_t n, int square, double* acc, hipStream_t s);
-hipError_t launch_loss_final(const double* acc, double log_det_total, float sigma, double denom, float* out, hipStream_t s);
+hipError_t launch_loss_final(const double* acc, double log_det_total, const float* log_det_dev, int n_dev, float sigma, double denom,
+                             float* out, hipStream_t s);
 
 }  // namespace wg

@@ -123,12 +123,54 @@ struct StartWgradArgs {
 
 hipError_t launch_plane_gemm(const PGemmArgs& a, hipStream_t s);
 
+// ---- training plumbing on the device (train_prep.hip): the module's own parameter tensors in, per-parameter gradients out.
+// One device table of pointers, section-major; sections 0..16 are the PARAMETERS in the library's canonical order
+// (wg_train_param_name), the rest are per-flow buffers of wg_train_weights / wg_train_grads.
+enum PrepSec : int {
+  SEC_IN_V = 0, SEC_IN_G, SEC_IN_B,      // in_layers[i]: weight (v or dense) [2C][C][3], g [2C] or null, bias [2C]     x FL
+  SEC_RS_V, SEC_RS_G, SEC_RS_B,          // res_skip_layers[i]: [2C or C][C][1], g, bias                                x FL
+  SEC_CO_V, SEC_CO_G, SEC_CO_B,          // cond_layer: [2C*nl][M8][1], g, bias                                         x n_flows
+  SEC_ST_V, SEC_ST_G, SEC_ST_B,          // start: [C][h_k][1], g, bias                                                 x n_flows
+  SEC_EN_W, SEC_EN_B, SEC_CV_W,          // end.weight [2h_k][C][1], end.bias [2h_k], convinv.conv.weight [c_k][c_k][1]  x n_flows
+  SEC_UP_W, SEC_UP_B,                    // upsample.weight [M][M][1024], upsample.bias [M]                              x 1
+  SEC_O_WSTART, SEC_O_BSTART, SEC_O_OINIT, SEC_O_W1X1,      // outputs of prepare (wg_train_weights per-flow pointers)   x n_flows
+  SEC_G_DSTART, SEC_G_DOINIT, SEC_G_DW1X1,                  // packed gradients (wg_train_grads per-flow pointers)       x n_flows
+  SEC_COUNT
+};
+constexpr int kPrepMaxFlows = 32;
+struct PrepArgs {
+  void* const* tab;          // device pointer table (prep_slot)
+  const long long* goff;     // per parameter slot: offset (floats) of its gradient in `flat`
+  float* flat;               // per-parameter gradients, canonical order
+  float *s_in, *s_co, *s_rs, *s_st;     // weight-norm row scales g / ||v||, followed by 1 / ||v|| (n_scale entries each)
+  float *wend8, *bsum, *wes;            // W_end zero-padded to 8 rows [nf][8][C], sum_i b_skip_i [nf][C], W_end.W_skip_i [FL][8][C]
+  float *b1, *b2, *bup;                 // wg_train_weights: b1 (pre-scaled), b2, bup
+  const float *dw1, *db1, *dw2, *db2, *dwes, *dwup, *dbup;    // wg_train_grads
+  long long layer_stride, flow_stride;
+  int C, M8, nl, nf, FL;
+  int hk[kPrepMaxFlows], ck[kPrepMaxFlows];
+  int n_scale[4];            // rows of the four weight-normed module classes (in_layers, cond_layer, res_skip_layers, start)
+};
+__host__ __device__ inline int prep_sec_len(int FL, int nf, int sec) {
+  return sec <= SEC_RS_B ? FL : (sec == SEC_UP_W || sec == SEC_UP_B) ? 1 : nf;
+}
+__host__ __device__ inline int prep_slot_n(int FL, int nf, int sec, int idx) {
+  int base = 0;
+  for (int q = 0; q < sec; ++q) base += prep_sec_len(FL, nf, q);
+  return base + idx;
+}
+__host__ __device__ inline int prep_slot(const PrepArgs& a, int sec, int idx) { return prep_slot_n(a.FL, a.nf, sec, idx); }
+hipError_t launch_prepare(const PrepArgs& a, hipStream_t s);
+hipError_t launch_param_grads(const PrepArgs& a, hipStream_t s);
+
 // weight packing (train.hip: pack_kernel), one launch per output tensor
 enum PackKind : int { PACK_A1 = 0, PACK_A2, PACK_ES, PACK_WAT, PACK_WBT, PACK_WCT, PACK_WUP };
 struct PackArgs {
   int kind;
   int C, M8, FL, NW;
   const float *w1, *w2, *wes, *wup;   // natural-order sources (include/waveglow_amd.h: wg_train_plain)
+  int native;                         // 1: w1 / w2 / wup are read from the module's own tensors instead (prep.tab, weight-norm
+  PrepArgs prep;                      //    scales applied on the fly): wg_train_prepare; wes is prep.wes either way
   _Float16 *dst, *dst2;               // PACK_A1: a1 (tap K-steps) and a1c (conditioning K-steps)
   size_t n_pieces;                    // 16-byte output pieces
 };

@@ -68,10 +68,21 @@ def _dense_weight(conv: nn.Module) -> torch.Tensor:
 class _Engine:
   """Owns one wg_handle and the packed device weights derived from a module's parameters."""
 
+  KERNEL_WIDTHS = (64, 128, 256, 512)          # n_channels the WN-layer kernel is instantiated for
+
   def __init__(self, hp: HParams, device: torch.device):
     lib = _lib.load()
+    # Any n_channels up to 512 (the reference takes any even number, model.py:78): the kernels run at the next
+    # instantiated width with the extra channels' weights and biases zero -- x_pad = 0, tanh(0) * sigmoid(0) = 0, res / skip
+    # add nothing: the results are exactly those of the unpadded network (inference and the no-grad forward; training
+    # takes the instantiated widths only).
+    self.n_channels = hp.n_channels
+    self.width = next((w for w in self.KERNEL_WIDTHS if w >= hp.n_channels), 0)
+    if not self.width or hp.n_channels < 1:
+      raise _lib.WgError(f"n_channels={hp.n_channels} unsupported (1..512)")
+    self.n_layers = hp.n_layers
     cfg = _lib.WgConfig(hp.n_mel_channels, hp.n_flows, hp.n_group, hp.n_early_every, hp.n_early_size,
-                        hp.n_layers, hp.n_channels, hp.kernel_size, 1024, 256)
+                        hp.n_layers, self.width, hp.kernel_size, 1024, 256)
     handle = C.c_void_p()
     _lib.check(lib.wg_create(C.byref(cfg), _lib.device_index(device), C.byref(handle)))
     self.lib = lib
@@ -82,6 +93,7 @@ class _Engine:
     self._train_pool: List[dict] = []          # training workspaces (saved activations), see train_workspace
     self._graphs: Dict[tuple, tuple] = {}      # captured hipGraphs of wg_infer, keyed by input shape / dtype / sigma
     self._graphs_sig: Optional[tuple] = None   # weight signature the graphs were captured with
+    self.cache: Dict[tuple, object] = {}       # small per-handle lookups (canonical parameter names of the training direction)
 
   def __del__(self):
     try:
@@ -96,10 +108,41 @@ class _Engine:
       name = self.lib.wg_expected_tensor_name(self.handle, i).decode()
       if name not in tensors:
         raise _lib.WgError(f"missing weight '{name}'")
-      t = tensors[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+      t = tensors[name].detach().to(device="cpu", dtype=torch.float32)
+      if self.width != self.n_channels:
+        t = self._pad_channels(name, t)
+      t = t.contiguous()
       shape = (C.c_int64 * t.dim())(*t.shape)
       _lib.check(self.lib.wg_set_tensor(self.handle, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
     _lib.check(self.lib.wg_finalize(self.handle))
+
+  def _pad_channels(self, name: str, t: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the WN channel axes of one dense (470-key form) tensor from n_channels to the kernel width.  The gate
+    halves (tanh rows | sigmoid rows, model.py:13-20) and the res | skip halves (model.py:131-136) are padded separately."""
+    Cc, W, nl = self.n_channels, self.width, self.n_layers
+    pad = torch.nn.functional.pad
+    parts = name.split(".")
+    if parts[0] != "WN":
+      return t
+    mod, leaf = parts[2], parts[-1]
+
+    def halves(x, n_halves):            # [n_halves * Cc, ...] -> [n_halves * W, ...]
+      x = x.reshape(n_halves, Cc, *x.shape[1:])
+      return pad(x, (0, 0) * (x.dim() - 2) + (0, W - Cc)).reshape(n_halves * W, *x.shape[2:])
+
+    if mod == "start":
+      return halves(t, 1)
+    if mod == "end":
+      return pad(t, (0, 0, 0, W - Cc)) if leaf == "weight" else t            # [2h, C, 1]: the input-channel axis
+    if mod == "cond_layer":
+      return halves(t, 2 * nl)
+    if mod == "in_layers":
+      t = halves(t, 2)
+      return pad(t, (0, 0, 0, W - Cc)) if leaf == "weight" else t            # [2W, C, 3] -> [2W, W, 3]
+    if mod == "res_skip_layers":
+      t = halves(t, t.shape[0] // Cc)
+      return pad(t, (0, 0, 0, W - Cc)) if leaf == "weight" else t
+    return t
 
   def workspace(self, kind: str, nbytes: int, key: Tuple[int, int, int]) -> torch.Tensor:
     """One cached workspace (the last shape's).  A captured hipGraph bakes its workspace's device pointer in, so
@@ -355,14 +398,16 @@ class _LossFn(torch.autograd.Function):
     lib = _lib.load()
     z32 = z.float().contiguous()
     ls32 = [t.float().contiguous() for t in log_s]
-    ld = (C.c_float * n_ls)(*[float(x) for x in log_det])
     ptrs = (C.c_void_p * n_ls)(*[t.data_ptr() for t in ls32])
     sizes = (C.c_int64 * n_ls)(*[t.numel() for t in ls32])
     out = torch.empty((), dtype=torch.float32, device=z.device)
     ws = torch.empty(16, dtype=torch.uint8, device=z.device)
     stream = torch.cuda.current_stream(z.device).cuda_stream
-    _lib.check(lib.wg_loss(z32.data_ptr(), z32.numel(), ptrs, sizes, n_ls, ld, float(sigma), out.data_ptr(),
-                           ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+    # log_det_W stays on the device (one small stack): reading the scalars on the host would synchronise the stream
+    # between forward and backward in every training step
+    ld = torch.stack([x.detach().reshape(()).to(device=z.device, dtype=torch.float32) for x in log_det]).contiguous()
+    _lib.check(lib.wg_loss_dev(z32.data_ptr(), z32.numel(), ptrs, sizes, n_ls, ld.data_ptr(), float(sigma), out.data_ptr(),
+                               ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
     ctx.save_for_backward(z)
     ctx.sigma, ctx.n_ls = float(sigma), n_ls
     ctx.meta = [(t.shape, t.dtype) for t in log_s] + [(t.shape, t.dtype) for t in log_det]

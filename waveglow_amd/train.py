@@ -215,52 +215,68 @@ def plain_fragments(mat: torch.Tensor, NW: int) -> torch.Tensor:
   return v.permute(0, 4, 5, 1, 2, 6, 7, 3, 8).contiguous()                  # [FL, ks, u1, w, mb, k2, hh, r, j]
 
 
-class _Weights:
-  """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward).  The fp16
-  fragment tensors are filled by the library itself (``wg_train_pack``: one pass per tensor); what is left here are the
-  small fp32 vectors.  ``wn_forward_fragments`` / ``plain_fragments`` / ``to_fragments`` above are the same layouts
-  written as torch index arithmetic: the tests hold the pack kernel to them bit for bit."""
+def canonical_params(model, eng):
+  """(tensors in the library's canonical order, weight_normed flag) for wg_train_prepare / wg_train_param_grads: the
+  module's own parameter tensors, looked up by state_dict key (include/waveglow_amd.h: wg_train_param_name)."""
+  wn = torch.nn.utils.parametrize.is_parametrized(model.WN[0].start, "weight")
+  key = ("train_param_names", wn)
+  names = eng.cache.get(key)
+  if names is None:
+    n = eng.lib.wg_train_param_count(eng.handle, int(wn))
+    names = [eng.lib.wg_train_param_name(eng.handle, int(wn), i).decode() for i in range(n)]
+    eng.cache[key] = names
+  byname = dict(model.named_parameters())
+  try:
+    tensors = [byname[n] for n in names]
+  except KeyError as e:
+    raise _lib.WgError(f"parameter {e} missing: the training direction needs every WN module in the same form "
+                       "(all weight-normed, or all dense after remove_weightnorm)")
+  for n, t in zip(names, tensors):
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
+      raise _lib.WgError(f"parameter {n}: the training direction takes contiguous float32 parameters on the GPU")
+  return names, tensors, wn
 
-  def __init__(self, model, packed, flow_c: List[int], NW: int, eng, stream):
+
+class _Weights:
+  """Device buffers + the ctypes struct handed to the library (kept alive between forward and backward).  Everything in
+  them -- fp16 fragment tensors and the small fp32 vectors -- is filled by the library itself from the module's own
+  parameter tensors (``wg_train_prepare``: weight norm, the W_end x W_skip fold, permutations, gate pre-scale, fragment
+  orders).  ``pack_weights`` / ``wn_forward_fragments`` / ``plain_fragments`` / ``to_fragments`` above are the same
+  computation written as torch ops: the tests hold the library to them."""
+
+  def __init__(self, model, tensors, wn: bool, flow_c: List[int], eng, stream):
     hp = model._hp
-    Cc, nf = hp.n_channels, model.n_flows
+    Cc, nf, nl = hp.n_channels, model.n_flows, hp.n_layers
     M8 = hp.n_mel_channels * 8
-    dev = packed[0].device
-    pm = _perms(Cc, M8, dev)
-    nat = [t.detach() for t in packed]
-    FL = nat[0].shape[0]
+    dev = tensors[0].device
+    FL = nf * nl
     K1 = 3 * Cc + M8
     h16 = lambda n: torch.empty(n, dtype=torch.float16, device=dev)
+    f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
     n_tap = 3 * Cc // 64
     self.a1, self.a1c = h16(FL * n_tap * 64 * 2 * Cc), h16(FL * (K1 // 64 - n_tap) * 64 * 2 * Cc)
     self.a2, self.es = h16(FL * Cc * Cc), h16(FL * 16 * Cc)
     self.wat, self.wbt = h16(FL * Cc * (Cc + 64)), h16(FL * Cc * 6 * Cc)
     self.wct, self.wup = h16(M8 * FL * 2 * Cc), h16(32 * M8 * 512)
-    scale = torch.cat([torch.full((Cc,), K_TANH_SCALE), torch.full((Cc,), K_SIGM_SCALE)]).to(nat[1])
-    self.b1 = (nat[1] * scale[None, :]).float().contiguous()
-    self.b2 = nat[3].float().contiguous()
-    self.bup = nat[6].index_select(0, pm.m8).float()
-    start5, out_init, w1x1 = nat[7].index_select(2, pm.c), nat[8], nat[9]
-    # per-flow operands as rows of one tensor per shape run (a copy per flow and operand was 48 tiny kernels per step)
-    self.wstart, self.w1x1 = [None] * nf, [None] * nf
-    for c, ks in _shape_runs(flow_c):
-      ws = start5[ks[0]:ks[-1] + 1, :c // 2].transpose(1, 2).float().contiguous()           # [n, C, h]
-      w1 = w1x1[ks[0]:ks[-1] + 1, :c, :c].float().contiguous()
-      for j, k in enumerate(ks):
-        self.wstart[k], self.w1x1[k] = ws[j], w1[j]
-    bst, oi = start5[:, 4].float().contiguous(), out_init.float().contiguous()
-    self.bstart = [bst[k] for k in range(nf)]
-    self.out_init = [oi[k] for k in range(nf)]
+    self.b1, self.b2, self.bup = f32(FL, 2 * Cc), f32(FL, Cc), f32(M8)
+    # per-flow operands as rows of one buffer each
+    small = f32(nf, Cc * 4 + Cc + 8 + 64)
+    self._small = small
+    self.wstart = [small[k, :Cc * (c // 2)] for k, c in enumerate(flow_c)]
+    self.bstart = [small[k, 4 * Cc:5 * Cc] for k in range(nf)]
+    self.out_init = [small[k, 5 * Cc:5 * Cc + 8] for k in range(nf)]
+    self.w1x1 = [small[k, 5 * Cc + 8:5 * Cc + 8 + c * c] for k, c in enumerate(flow_c)]
     arr = lambda ts: (C.c_void_p * nf)(*[t.data_ptr() for t in ts])
     self._arrs = [arr(self.wstart), arr(self.bstart), arr(self.out_init), arr(self.w1x1)]
     self.struct = _lib.WgTrainWeights(_ptr(self.a1), _ptr(self.a1c), _ptr(self.b1), _ptr(self.a2), _ptr(self.b2), _ptr(self.es),
                                       _ptr(self.wat), _ptr(self.wbt), _ptr(self.wct), _ptr(self.wup), _ptr(self.bup),
                                       C.cast(self._arrs[0], C.c_void_p), C.cast(self._arrs[1], C.c_void_p),
                                       C.cast(self._arrs[2], C.c_void_p), C.cast(self._arrs[3], C.c_void_p))
-    src = [nat[0].float().contiguous(), nat[2].float().contiguous(), nat[4].float().contiguous(), nat[5].float().contiguous()]
-    plain = _lib.WgTrainPlain(*[_ptr(t) for t in src])
-    _lib.check(eng.lib.wg_train_pack(eng.handle, C.byref(plain), C.byref(self.struct), C.c_void_p(stream)))
-    self._src = src                                        # alive until the pack kernels have run (stream-ordered free is fine too)
+    self.wn = int(wn)
+    self.params = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    self.aux = torch.empty(eng.lib.wg_train_prepare_bytes(eng.handle), dtype=torch.uint8, device=dev)
+    _lib.check(eng.lib.wg_train_prepare(eng.handle, self.params, self.wn, C.byref(self.struct), _ptr(self.aux),
+                                        self.aux.numel(), C.c_void_p(stream)))
 
 
 class _SlotGuard:
@@ -392,19 +408,21 @@ def flow_backward_schedule(n_flows: int, run_flow, bufs, group=None) -> None:
 
 
 class _TrainFn(torch.autograd.Function):
+  """Inputs: the module's parameters in the library's canonical order (``canonical_params``); outputs (z, log_s...).
+  backward() returns one gradient per parameter, each a view of ONE flat buffer the library fills."""
+
   @staticmethod
-  def forward(ctx, model, mel, audio, scale, *packed):
+  def forward(ctx, model, mel, audio, scale, wn, *params):
     eng = model._get_engine(mel.device, need_weights=False)
     lib = eng.lib
     B, M, F_ = mel.shape
     S = audio.shape[1]
     L = S // model.n_group
     flow_c = model.flow_channels()
-    NW = int(lib.wg_wn_waves(model._hp.n_channels))
-    if NW <= 0:
+    if int(lib.wg_wn_waves(model._hp.n_channels)) <= 0:
       raise _lib.WgError(f"n_channels={model._hp.n_channels} unsupported (64, 128, 256, 512)")
     stream = torch.cuda.current_stream(mel.device).cuda_stream
-    wts = _Weights(model, packed, flow_c, NW, eng, stream)
+    wts = _Weights(model, [p.detach() for p in params], wn, flow_c, eng, stream)
     z = torch.empty((B, model.n_group, L), dtype=torch.float32, device=mel.device)
     log_s = [torch.empty((B, c // 2, L), dtype=torch.float32, device=mel.device) for c in flow_c]
     nbytes = lib.wg_train_workspace_bytes(eng.handle, B, F_, S)
@@ -417,7 +435,7 @@ class _TrainFn(torch.autograd.Function):
                                     1 if fresh else 0, _ptr(ws), ws.numel(), C.c_void_p(stream)))
     ctx.model, ctx.wts, ctx.ws, ctx.dims, ctx.audio, ctx.guard = model, wts, ws, (B, F_, S), audio, _SlotGuard(slot)
     ctx.scale = float(scale) if scale else float(2.0 ** round(math.log2(z.numel())))
-    ctx.shapes = [t.shape for t in packed]
+    ctx.shapes = [t.shape for t in params]
     return (z, *log_s)
 
   @staticmethod
@@ -446,15 +464,14 @@ class _TrainFn(torch.autograd.Function):
                                        C.c_void_p(stream)))
     else:
       # Data parallel: the backward pass is cut at flow boundaries and every flow's gradients -- ONE contiguous region
-      # of the flat buffer -- are all-reduced right behind it (flow_backward_schedule).  The packing ops that follow in
-      # autograd are linear in these gradients, so averaging here equals averaging the parameter gradients (the logdet
-      # term of the 1x1 weights is identical on every rank).
+      # of the flat buffer -- are all-reduced right behind it (flow_backward_schedule).  What follows (weight-norm
+      # backward, the fold's chain rule: wg_train_param_grads) is linear in these gradients, so averaging here equals
+      # averaging the parameter gradients (the logdet term of the 1x1 weights is identical on every rank).
       def run_flow(k):
         _lib.check(lib.wg_train_backward_flows(eng.handle, C.byref(wts.struct), C.byref(gstruct), gz_ptr, gl_arr,
                                                C.c_float(ctx.scale), _ptr(ctx.audio), B, F_, S, _ptr(ctx.ws),
                                                ctx.ws.numel(), k, k, C.c_void_p(stream)))
       flow_backward_schedule(nf, run_flow, bufs, group)
-    ctx.wts = None
     ctx.guard.release()
     # Overflow of the fp16 gradient planes (the automatic scale 2^round(log2 N) assumes the reference's MEAN loss; a
     # loss with another normalisation needs model.grad_scale) or inf / nan inputs: every gradient tensor is checked,
@@ -463,9 +480,19 @@ class _TrainFn(torch.autograd.Function):
     # (one reduction: inf / nan anywhere makes the sum non-finite, and 8.6e7 finite fp32 values cannot overflow it)
     model.grad_finite = torch.isfinite(bufs.flat.sum())
     if os.environ.get("WG_TRAIN_CHECK_FINITE") == "1" and not bool(model.grad_finite):
+      ctx.wts = None
       raise _lib.WgError(nonfinite_message(ctx.scale))
-    grads = bufs.packed_grads()
-    return (None, None, None, None, *grads)
+    # one gradient per parameter, views of one flat buffer in the canonical order
+    sizes = [math.prod(sh) for sh in ctx.shapes]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    if os.environ.get("WG_TRAIN_POISON_GRADS") == "1":
+      flat.fill_(float("nan"))
+    _lib.check(lib.wg_train_param_grads(eng.handle, wts.params, wts.wn, C.byref(gstruct), _ptr(wts.aux), wts.aux.numel(),
+                                        _ptr(flat), C.c_void_p(stream)))
+    ctx.wts = None
+    model.last_packed_grads = bufs if os.environ.get("WG_TRAIN_KEEP_PACKED") == "1" else None      # tests
+    grads = [v.view(sh) for v, sh in zip(flat.split(sizes), ctx.shapes)]
+    return (None, None, None, None, None, *grads)
 
 
 def nonfinite_message(scale: float) -> str:
@@ -486,8 +513,12 @@ def train_forward(model, mel: torch.Tensor, audio: torch.Tensor, grad_scale: flo
   S = S - S % model.n_group                            # unfold drops the remainder (model.py:191,195)
   audio = audio[:, :S].contiguous()
   mel = mel.contiguous()
-  packed = pack_weights(model)
-  out = _TrainFn.apply(model, mel, audio, grad_scale, *packed)
+  eng = model._get_engine(mel.device, need_weights=False)
+  if eng.width != eng.n_channels:
+    raise _lib.WgError(f"n_channels={eng.n_channels}: the training direction takes the kernel widths {eng.KERNEL_WIDTHS} only "
+                       "(inference and the no-grad forward zero-pad other widths)")
+  _names, tensors, wn = canonical_params(model, eng)
+  out = _TrainFn.apply(model, mel, audio, grad_scale, wn, *tensors)
   z, log_s = out[0], list(out[1:])
   L = S // model.n_group
   return z, log_s, _log_det_w(model, B * L)
