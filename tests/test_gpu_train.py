@@ -170,12 +170,12 @@ def test_train_step_half_batch_chains(over, B, monkeypatch):
   _check(g_c, g_ref, f"chains c{hp.n_channels}")
 
 
-@pytest.mark.parametrize("slabs", ["1", "3", "7", "32", "50", "128"])
+@pytest.mark.parametrize("slabs", ["1", "3,5", "7", "32", "50,64", "128"])
 def test_train_step_every_slab_shape(slabs, monkeypatch):
   """The weight-gradient kernel cuts the rows (32 phases x Rp) into n_slabs contiguous ranges of 32-row steps, one fp32
   partial tile per workgroup and range; the launcher picks n_slabs = CUs / tiles.  Here (Rp = 128: 4 steps per phase, 128
   in all) pinned to: everything in one slab, ranges that start and end inside phases (3, 7, 50), one phase per slab (32)
-  and one step per slab (128) -- against the oracle."""
+  and one step per slab (128), the two jobs of a layer with equal or different slab counts -- against the oracle."""
   from oracle import torch_oracle as O
   monkeypatch.setenv("WG_TRAIN_SLABS", slabs)
   hp, sd, mel, wav = _setup(dict(n_layers=3, n_flows=2, n_early_every=1, n_early_size=2), 3, 11, 8, crop=56)

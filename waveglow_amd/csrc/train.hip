@@ -473,7 +473,7 @@ struct WgradLaunch {
   WgradJob job[2];
   int tiles[2];           // tiles of each job (the second may be 0)
   RowGeom g;
-  int n_slabs;
+  int n_slabs[2];
   unsigned long long* stamps;   // diagnostic builds only (-DWGR_STAMPS): [workgroups][8]
 };
 #ifdef WGR_STAMPS
@@ -492,13 +492,13 @@ struct WgradLaunch {
 // and 61 branches per step, 1 900 cycles of scalar issue per wave beside 512 cycles of MFMA.)
 template <bool SHAPE_B, bool EXTRA>
 __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob& a, const WgradTile tl, const int slab,
-                                           const int tile, const int job_tiles, _Float16* wg_smem) {
+                                           const int tile, const int job_tiles, const int n_slabs, _Float16* wg_smem) {
   constexpr int MC = SHAPE_B ? 8 : 4, KCW = SHAPE_B ? 2 : 4;
   constexpr int NS = (MC + KCW) / 2;              // staging pieces per wave and step; waves 0-3 one more with EXTRA
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const RowGeom& g = L.g;
   const int wm = SHAPE_B ? (w >> 1) : (w >> 2), wk = SHAPE_B ? (w & 1) : (w & 3);
-  const bool do_bias = tl.bias_duty && a.bias_out != nullptr;
+  const int bias_chunks = a.bias_out != nullptr ? tl.bias_chunks : 0;
   const size_t R64 = (size_t)g.R * 64;
   const int m_chunks = a.m_chunks, k_chunks = a.k_chunks;
 
@@ -537,7 +537,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
   // ---- this slab's range of steps (global step = phase * steps_per_phase + step)
   const int spp = g.Rp / WG_STEP;
   const long long total = (long long)kPhases * spp;
-  const int gs0 = (int)((long long)slab * total / L.n_slabs), gs1 = (int)((long long)(slab + 1) * total / L.n_slabs);
+  const int gs0 = (int)((long long)slab * total / n_slabs), gs1 = (int)((long long)(slab + 1) * total / n_slabs);
   const int n_steps = gs1 - gs0;
 
   const char* src[NS + 1];                        // running source pointers: + 4 KiB per step inside a phase
@@ -609,13 +609,14 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
     for (int j = 0; j < 8; ++j) o[j] = v;
     return o;
   };
-  // Column sums: fragments i = wk (mod KCW) of this wave's G rows are summed by this wave (bit i), the extra plane's by
-  // wave (0, 0) (bit 8).  A fragment of a slice past the matrix is never summed.
+  // Column sums of the G chunks this tile is responsible for (WgradTile::bias_chunks): fragments i = wk (mod KCW) of this
+  // wave's G rows are summed by this wave (bit i), the extra plane's by wave (0, 0) (bit 8).  A fragment of a slice past the
+  // matrix is never summed.
   unsigned bias_mask = 0;
-  if (do_bias) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if ((i & (KCW - 1)) == wk && tl.mc0 + 2 * wm + (i >> 2) < m_chunks) bias_mask |= 1u << i;
+  for (int i = 0; i < 8; ++i) {
+    const int cl = 2 * wm + (i >> 2);            // chunk of fragment i inside the tile
+    if (((bias_chunks >> cl) & 1) && (i & (KCW - 1)) == wk && tl.mc0 + cl < m_chunks) bias_mask |= 1u << i;
   }
   const bool extra_wave = EXTRA && wm == 0;
   if (extra_wave && wk == 0 && a.extra_bias_out) bias_mask |= 256u;
@@ -738,7 +739,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WGR_STAMP(5);
   if (tid == 0 && L.stamps) {
-    L.stamps[(size_t)blockIdx.x * 32 + 6] = ((unsigned long long)tile << 32) | (unsigned)slab;
+    L.stamps[(size_t)blockIdx.x * 32 + 6] = ((unsigned long long)(tile + (EXTRA ? 100 : 0)) << 32) | (unsigned)slab;
     L.stamps[(size_t)blockIdx.x * 32 + 7] = ((unsigned long long)n_steps << 32);
   }
 #endif
@@ -750,20 +751,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int tid = threadIdx.x;
 #endif
   WGR_STAMP(0);
-  const int T = L.tiles[0] + L.tiles[1];
-  const unsigned wgid = xcd_order(blockIdx.x, gridDim.x);
-  const int slab = (int)(wgid / (unsigned)T), tt = (int)(wgid - (unsigned)slab * (unsigned)T);
-  const bool second = tt >= L.tiles[0];
+  // workgroups of job 0 first (tiles[0] x n_slabs[0]), then job 1's; inside a job the tiles of one slab are consecutive
+  const unsigned n0 = (unsigned)(L.tiles[0] * L.n_slabs[0]);
+  const bool second = blockIdx.x >= n0;
+  const unsigned jb = second ? blockIdx.x - n0 : blockIdx.x, jn = second ? gridDim.x - n0 : n0;
+  const unsigned wgid = xcd_order(jb, jn);
   const WgradJob& a = second ? L.job[1] : L.job[0];
-  const int tile = second ? tt - L.tiles[0] : tt, job_tiles = second ? L.tiles[1] : L.tiles[0];
+  const int job_tiles = second ? L.tiles[1] : L.tiles[0], n_slabs = second ? L.n_slabs[1] : L.n_slabs[0];
+  const int slab = (int)(wgid / (unsigned)job_tiles), tile = (int)(wgid - (unsigned)slab * (unsigned)job_tiles);
   const WgradTile tl = wgrad_tile(a.m_chunks, a.k_chunks, tile);
   const bool extra = tl.extra_duty && a.G_extra != nullptr;
   if (tl.shape) {
-    if (extra) wgrad_body<true, true>(L, a, tl, slab, tile, job_tiles, wg_smem);
-    else wgrad_body<true, false>(L, a, tl, slab, tile, job_tiles, wg_smem);
+    if (extra) wgrad_body<true, true>(L, a, tl, slab, tile, job_tiles, n_slabs, wg_smem);
+    else wgrad_body<true, false>(L, a, tl, slab, tile, job_tiles, n_slabs, wg_smem);
   } else {
-    if (extra) wgrad_body<false, true>(L, a, tl, slab, tile, job_tiles, wg_smem);
-    else wgrad_body<false, false>(L, a, tl, slab, tile, job_tiles, wg_smem);
+    if (extra) wgrad_body<false, true>(L, a, tl, slab, tile, job_tiles, n_slabs, wg_smem);
+    else wgrad_body<false, false>(L, a, tl, slab, tile, job_tiles, n_slabs, wg_smem);
   }
 }
 
@@ -780,21 +783,24 @@ hipError_t check_wgrad(const WgradJob& a) {
 
 unsigned long long* g_wgrad_stamps = nullptr;     // diagnostic builds: set through wg_debug_set_stamp_buffer
 
-hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int n_slabs, hipStream_t s) {
-  if (n_jobs < 1 || n_jobs > 2 || g.Rp % WG_STEP || n_slabs < 1 || (long long)n_slabs > (long long)kPhases * (g.Rp / WG_STEP))
-    return hipErrorInvalidValue;
+hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, const int* n_slabs, hipStream_t s) {
+  if (n_jobs < 1 || n_jobs > 2 || g.Rp % WG_STEP || !n_slabs) return hipErrorInvalidValue;
   WgradLaunch L;
+  unsigned grid = 0;
   for (int j = 0; j < 2; ++j) {
     L.job[j] = jobs[j < n_jobs ? j : 0];
     L.tiles[j] = 0;
+    L.n_slabs[j] = 1;
     if (j < n_jobs) {
       const hipError_t e = check_wgrad(jobs[j]);
       if (e != hipSuccess) return e;
+      if (n_slabs[j] < 1 || (long long)n_slabs[j] > (long long)kPhases * (g.Rp / WG_STEP)) return hipErrorInvalidValue;
       L.tiles[j] = wgrad_tiles(jobs[j].m_chunks, jobs[j].k_chunks);
+      L.n_slabs[j] = n_slabs[j];
+      grid += (unsigned)(L.tiles[j] * n_slabs[j]);
     }
   }
   L.g = g;
-  L.n_slabs = n_slabs;
   L.stamps = g_wgrad_stamps;
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
   int cur_dev = 0;
@@ -804,7 +810,7 @@ hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int 
     if (e != hipSuccess) return e;
     attr_done_dev[cur_dev] = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((L.tiles[0] + L.tiles[1]) * n_slabs)), dim3(512), WD_LDS_BYTES, s, L);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(512), WD_LDS_BYTES, s, L);
   return hipGetLastError();
 }
 

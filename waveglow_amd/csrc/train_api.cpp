@@ -77,7 +77,7 @@ struct TrainWs {
   size_t bytes;
 };
 
-TrainWs carve(const wg_config& c, const RowGeom& g, int n_slabs, char* base) {
+TrainWs carve(const wg_config& c, const RowGeom& g, const int* n_slabs, char* base) {
   TrainWs w;
   const int C = c.n_channels, FL = c.n_flows * c.n_layers, M8 = c.n_mel_channels * 8;
   const size_t chunk = (size_t)g.R * 64;           // elements of one 64-channel plane
@@ -103,12 +103,12 @@ TrainWs carve(const wg_config& c, const RowGeom& g, int n_slabs, char* base) {
   const int cc = C / 64, mc = M8 / 64;
   const size_t t1 = (size_t)wgrad_tiles(2 * cc, 3 * cc + mc), t2 = (size_t)wgrad_tiles(cc, cc);
   for (int q = 0; q < 2; ++q) {
-    w.slab[q] = (float*)take((size_t)n_slabs * t1 * kWgradTileFloats * 4);
-    w.slab2[q] = (float*)take((size_t)n_slabs * t2 * kWgradTileFloats * 4);
-    w.part[q] = (float*)take((size_t)n_slabs * 2 * C * 4);
-    w.part2[q] = (float*)take((size_t)n_slabs * C * 4);
-    w.ext[q] = (float*)take((size_t)n_slabs * 16 * C * 4);
-    w.extb[q] = (float*)take((size_t)n_slabs * 16 * 4);
+    w.slab[q] = (float*)take((size_t)n_slabs[0] * t1 * kWgradTileFloats * 4);
+    w.slab2[q] = (float*)take((size_t)n_slabs[1] * t2 * kWgradTileFloats * 4);
+    w.part[q] = (float*)take((size_t)n_slabs[0] * 2 * C * 4);
+    w.part2[q] = (float*)take((size_t)n_slabs[1] * C * 4);
+    w.ext[q] = (float*)take((size_t)n_slabs[1] * 16 * C * 4);
+    w.extb[q] = (float*)take((size_t)n_slabs[1] * 16 * 4);
   }
   w.slab_up = (float*)take((size_t)kPhases * wgrad_tiles(mc, 8) * kWgradTileFloats * 4);
   w.part3 = (float*)take(max_sz(max_sz((size_t)flow_bwd_workgroups(g) * 64, (size_t)start_wgrad_workgroups(g) * 5 * C),
@@ -125,7 +125,7 @@ struct Ctx {
   int C, FL, M8, K1, nl;
   int n_cu;
   int halves;      // 2: the batch runs as two independent half-batch chains (see setup)
-  int n_slabs;     // row ranges of the weight-gradient launches (see setup)
+  int n_slabs[2];  // row ranges of the two jobs of a weight-gradient launch (see setup)
   bool serial;     // WG_TRAIN_SERIAL=1: everything on the caller's stream (profiling of single kernels, A/B runs)
 };
 
@@ -185,20 +185,27 @@ int setup(wg_handle* h, int32_t B, int32_t n_frames, int32_t audio_len, void* wo
     const char* se = getenv("WG_TRAIN_SERIAL");
     x.serial = se && *se == '1';
   }
-  // Slabs of the weight-gradient launches (train.hip: wgrad_kernel): a layer's (tiles of d W1 + d W2) x n_slabs workgroups
-  // should be ONE round of one workgroup per CU -- n_slabs = CUs / tiles (config 4: 12 tiles -> 21 slabs = 252 workgroups).
+  // Slabs of the weight-gradient launches (train.hip: wgrad_kernel): a layer's workgroups -- tiles of d W1 x its slabs + tiles
+  // of d W2 x its slabs -- should be ONE round of one workgroup per CU, all equally long.  d W1 gets CUs / (all tiles) slabs;
+  // d W2, whose steps cost ~17 % more (the extra d out plane, its column sums), gets the CUs that are left: more, shorter
+  // slabs (config 4: 11 tiles x 21 slabs + 1 tile x 25 slabs = 256 workgroups of 110 / 92 steps).
   {
     const int cc = c.n_channels / 64, mc = c.n_mel_channels * 8 / 64;
-    const int tiles = wgrad_tiles(2 * cc, 3 * cc + mc) + wgrad_tiles(cc, cc);
+    const int t1 = wgrad_tiles(2 * cc, 3 * cc + mc), t2 = wgrad_tiles(cc, cc);
     const long long total_steps = (long long)kPhases * (x.g.Rp / 32);
-    long long ns = x.n_cu / tiles;
-    if (const char* e = getenv("WG_TRAIN_SLABS")) {      // tests: pin the number of slabs
-      const int v = atoi(e);
-      if (v >= 1) ns = v;
+    long long s1 = x.n_cu / (t1 + t2), s2;
+    if (s1 < 1) s1 = 1;
+    s2 = ((long long)x.n_cu - s1 * t1) / t2;
+    if (s2 < s1) s2 = s1;
+    if (const char* e = getenv("WG_TRAIN_SLABS")) {      // tests: pin the number of slabs, "<d W1>[,<d W2>]"
+      int a_ = 0, b_ = 0;
+      const int n = sscanf(e, "%d,%d", &a_, &b_);
+      if (n >= 1 && a_ >= 1) { s1 = a_; s2 = (n == 2 && b_ >= 1) ? b_ : a_; }
     }
-    if (ns < 1) ns = 1;
-    if (ns > total_steps) ns = total_steps;
-    x.n_slabs = (int)ns;
+    if (s1 > total_steps) s1 = total_steps;
+    if (s2 > total_steps) s2 = total_steps;
+    x.n_slabs[0] = (int)s1;
+    x.n_slabs[1] = (int)s2;
   }
   x.w = carve(c, x.g, x.n_slabs, (char*)workspace);
   if (workspace && x.w.bytes > workspace_bytes) return wg_set_error(WG_ERR_WORKSPACE, "training workspace too small");
@@ -487,7 +494,7 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     if (!(sW = wg_internal_aux_stream(h, 1))) return wg_set_error(WG_ERR_HIP, "cannot create the weight-gradient stream");
     if (!(sR = wg_internal_aux_stream(h, 2))) return wg_set_error(WG_ERR_HIP, "cannot create the slab-reduction stream");
   }
-  const int n_slabs = x.n_slabs;
+  const int* const n_slabs = x.n_slabs;
   int BNw = wn_block_n(C);
   if (BNw == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)n_cu) BNw = 64;
   if (const char* e = getenv("WG_FORCE_BN")) {
@@ -642,24 +649,24 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         SlabSeg seg[kMaxSlabSegs];
         int n_seg = 0;
         const size_t n1 = (size_t)2 * C * K1;
-        auto add_flat = [&](const float* slabs, size_t stride, size_t n, float* out, int row_len, int perm) {
-          seg[n_seg++] = make_seg(slabs, n_slabs, stride, n, inv, out, row_len, perm);
+        auto add_flat = [&](int job, const float* slabs, size_t stride, size_t n, float* out, int row_len, int perm) {
+          seg[n_seg++] = make_seg(slabs, n_slabs[job], stride, n, inv, out, row_len, perm);
         };
-        auto add_blocked = [&](const float* slabs, int m_ch, int k_ch, float* out) {
-          SlabSeg q = make_seg(slabs, n_slabs, (size_t)wgrad_tiles(m_ch, k_ch) * kWgradTileFloats,
+        auto add_blocked = [&](int job, const float* slabs, int m_ch, int k_ch, float* out) {
+          SlabSeg q = make_seg(slabs, n_slabs[job], (size_t)wgrad_tiles(m_ch, k_ch) * kWgradTileFloats,
                                (size_t)wgrad_tiles(m_ch, k_ch) * kWgradTileFloats, inv, out, k_ch * 64, 3);
           q.blocked = 1; q.m_chunks = m_ch; q.k_chunks = k_ch; q.n_groups = 1;
           seg[n_seg++] = q;
         };
-        add_blocked(w.slab[set], 2 * cc, 3 * cc + mc, gr->dw1 + gofs(fl, n1));
-        add_flat(w.part[set], (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
+        add_blocked(0, w.slab[set], 2 * cc, 3 * cc + mc, gr->dw1 + gofs(fl, n1));
+        add_flat(0, w.part[set], (size_t)2 * C, (size_t)2 * C, gr->db1 + gofs(fl, (size_t)2 * C), 2 * C, 2);
         if (gx) {
-          add_blocked(w.slab2[set], cc, cc, gr->dw2 + gofs(fl, (size_t)C * C));
-          add_flat(w.part2[set], (size_t)C, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
+          add_blocked(1, w.slab2[set], cc, cc, gr->dw2 + gofs(fl, (size_t)C * C));
+          add_flat(1, w.part2[set], (size_t)C, (size_t)C, gr->db2 + gofs(fl, (size_t)C), C, 2);
         }
-        add_flat(w.ext[set], (size_t)16 * C, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
+        add_flat(1, w.ext[set], (size_t)16 * C, (size_t)8 * C, gr->dwes + gofs(fl, (size_t)8 * C), C, 2);
         // d out_init = sum over columns of (d b | d log_s), once per flow
-        if (i == 0) add_flat(w.extb[set], 16, 8, gr->dout_init[k], 0, 0);
+        if (i == 0) add_flat(1, w.extb[set], 16, 8, gr->dout_init[k], 0, 0);
         TR_ORDER(wait_for(sR, l_done[set]));
         TR_TRY(launch_slab_reduce_multi(seg, n_seg, sR));
         TR_ORDER(mark(sR, r_done[set], 14 + set));
@@ -750,7 +757,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     a.k_chunks = 8;
     a.slabs = w.slab_up;
     a.bias_out = w.part3;
-    TR_TRY(launch_wgrad(&a, 1, g, kPhases, s));
+    const int up_slabs = kPhases;
+    TR_TRY(launch_wgrad(&a, 1, g, &up_slabs, s));
     SlabSeg sg[2];
     const size_t tile_n = (size_t)wgrad_tiles(mc, 8) * kWgradTileFloats;
     sg[0] = make_seg(w.slab_up, kPhases, tile_n, tile_n, inv, gr->dwup, 512, 1);      // rows to natural order, columns are mel taps

@@ -64,7 +64,8 @@ constexpr int kWgradTileFloats = 8 * 32 * 64 * 4;   // 8 waves x 32 accumulator 
 struct WgradTile {
   int shape;                // 0: 4 G chunks x 4 X chunks (waves 2 x 4); 1: 8 x 2 (waves 4 x 2); a wave owns 2 x 1 chunks
   int mc0, kc0;             // first G / X chunk
-  int bias_duty;            // this tile's workgroups also sum G over the rows (done once per G chunk)
+  int bias_chunks;          // bit c: this tile's workgroups also sum G chunk mc0 + c over the rows (every chunk is summed by
+                            // exactly one tile of its row of tiles: spread over the row, so that no tile is much slower)
   int extra_duty;           // ... and multiply G_extra with their X chunks (done once per X chunk)
 };
 __host__ __device__ inline int wgrad_tiles(int m_chunks, int k_chunks) {
@@ -75,11 +76,15 @@ __host__ __device__ inline WgradTile wgrad_tile(int m_chunks, int k_chunks, int 
   const int gxA = (m_chunks + 3) / 4, gyA = k_chunks / 4, nA = gxA * gyA, gxB = (m_chunks + 7) / 8;
   WgradTile q;
   if (t < nA) {
-    const int by = t / gxA, bx = t - by * gxA;
-    q.shape = 0; q.mc0 = 4 * bx; q.kc0 = 4 * by; q.bias_duty = by == 0; q.extra_duty = bx == 0;
+    const int by = t / gxA, bx = t - by * gxA, spread = gyA < 4 ? gyA : 4;
+    q.shape = 0; q.mc0 = 4 * bx; q.kc0 = 4 * by; q.extra_duty = bx == 0;
+    q.bias_chunks = 0;
+    for (int c = 0; c < 4; ++c)
+      if (by < spread && c % spread == by) q.bias_chunks |= 1 << c;
   } else {
     const int u = t - nA, by = u / gxB, bx = u - by * gxB;
-    q.shape = 1; q.mc0 = 8 * bx; q.kc0 = 4 * gyA + 2 * by; q.bias_duty = gyA == 0 && by == 0; q.extra_duty = bx == 0;
+    q.shape = 1; q.mc0 = 8 * bx; q.kc0 = 4 * gyA + 2 * by; q.extra_duty = bx == 0;
+    q.bias_chunks = (gyA == 0 && by == 0) ? 0xff : 0;
   }
   return q;
 }
@@ -175,9 +180,10 @@ struct PackArgs {
   size_t n_pieces;                    // 16-byte output pieces
 };
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
-// one launch for up to two jobs (a layer's d W1 and its d W2 / end x skip: their tiles share the slab partition, so
-// (tiles of both) x n_slabs workgroups fill the chip in ONE round when n_slabs = CUs / tiles)
-hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, int n_slabs, hipStream_t s);
+// one launch for up to two jobs (a layer's d W1 and its d W2 / end x skip), each with its own slab count: sum_j tiles_j x
+// n_slabs[j] workgroups fill the chip in ONE round when that sum is the CU count, and a job whose steps cost more (the extra
+// plane) gets more, shorter slabs
+hipError_t launch_wgrad(const WgradJob* jobs, int n_jobs, const RowGeom& g, const int* n_slabs, hipStream_t s);
 // out[i] = scale * sum_{s < n_slabs} slabs[s * stride + i],  i < n  (fixed order: bitwise reproducible), for up to
 // kMaxSlabSegs independent (slabs, out) pairs in ONE launch: a layer's weight-gradient
 // launches leave six small-to-large slab sets behind, and six launches of a few microseconds each cost more in launch
