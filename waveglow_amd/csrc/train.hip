@@ -423,8 +423,8 @@ hipError_t launch_slab_reduce_multi(const SlabSeg* segs, int n_segs, hipStream_t
 //   * both jobs of a layer ride in one launch over the same slab partition; d (W_end W_skip) = d out x acts^T needs only
 //     16 rows of a fifth G plane: the d W2 tile stages that plane as one more slice and its first wave row spends 4 of
 //     its 36 MFMAs per step on it (`extra`) instead of a 256-row tile that would be 94 % padding;
-//   * bias gradients (column sums of G) ride on the matrix pipe: one MFMA per fragment against a 0/1 selector that
-//     drops the sum into row i of ONE 16 x 16 accumulator (4 registers for all of a wave's fragments);
+//   * bias gradients (column sums of G) ride on the matrix pipe: one MFMA per fragment against an all-ones operand, the
+//     duty spread over the tiles of a row of tiles and over the waves of a tile;
 //   * operands swapped (A = X fragment, B = G fragment): a lane's four results are four consecutive K' of one row, and
 //     the tile is stored in accumulator order, one contiguous KiB per store instruction (the round-2 epilogue wrote
 //     64-byte segments: 2 ms per step); slab_reduce un-blocks.
@@ -567,9 +567,17 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
   };
 
   typedef float f32x4v __attribute__((ext_vector_type(4)));
-  f32x4v acc[8][4], acce[4], accb;
+  constexpr int NB = 8 / KCW;      // fragments of its G rows a wave can be responsible for summing (one accumulator each)
+  f32x4v acc[8][4], acce[4], accb[NB], accbe;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) accb[j] = 0.0f;
+  for (int j = 0; j < 4; ++j) {
+    accbe[j] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) accb[q][j] = 0.0f;
+  }
+  half8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -600,14 +608,6 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
     const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q0 + 16 * 64));
     const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
     return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-  // selector for the column sums: A operand whose row r (= lane & 15) is all ones, everything else zero
-  auto selector = [&](int r) -> half8 {
-    const _Float16 v = (u == r) ? (_Float16)1.0f : (_Float16)0.0f;
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = v;
-    return o;
   };
   // Column sums of the G chunks this tile is responsible for (WgradTile::bias_chunks): fragments i = wk (mod KCW) of this
   // wave's G rows are summed by this wave (bit i), the extra plane's by wave (0, 0) (bit 8).  A fragment of a slice past the
@@ -654,11 +654,11 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
 #pragma unroll
       for (int k = 0; k < 4; ++k) acce[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k], ef, acce[k], 0, 0, 0);
     }
-    if (bias_mask) {    // one MFMA per fragment this wave sums
+    if (bias_mask) {    // one MFMA per fragment this wave sums, against all ones: every row of the result is the column sum
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (bias_mask & (1u << i)) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(i), af[i], accb, 0, 0, 0);
-      if (bias_mask & 256u) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(selector(8), ef, accb, 0, 0, 0);
+        if (bias_mask & (1u << i)) accb[i / KCW] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, af[i], accb[i / KCW], 0, 0, 0);
+      if (EXTRA && (bias_mask & 256u)) accbe = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ef, accbe, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -728,13 +728,13 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const WgradJob&
             make_float4(acce[k][0], acce[k][1], acce[k][2], acce[k][3]);
     }
   }
-  // the sum of fragment i sits in accumulator row i: lane group i >> 2, register i & 3
+  // column sums: every row of a bias accumulator holds them; lanes 0-15 (row 0) write
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int mch = tl.mc0 + 2 * wm + (i >> 2);
-    if ((bias_mask & (1u << i)) && g16 == (i >> 2)) a.bias_out[(size_t)slab * Mtot + mch * 64 + 16 * (i & 3) + u] = accb[i & 3];
+    if ((bias_mask & (1u << i)) && g16 == 0) a.bias_out[(size_t)slab * Mtot + mch * 64 + 16 * (i & 3) + u] = accb[i / KCW][0];
   }
-  if ((bias_mask & 256u) && g16 == 2) a.extra_bias_out[(size_t)slab * 16 + u] = accb[0];
+  if (EXTRA && (bias_mask & 256u) && g16 == 0) a.extra_bias_out[(size_t)slab * 16 + u] = accbe[0];
 #ifdef WGR_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WGR_STAMP(5);
@@ -1223,9 +1223,13 @@ hipError_t launch_flow_bwd_post(const FlowBwdArgs& a, hipStream_t s) {
 }
 
 // d Wstart[P][j] = sum_rows d x_0[row][P] a0[row][j],  d bstart[P] = sum_rows d x_0[row][P]     (model.py:117)
-// grid (Rp/128, 32): 128 plane rows of one phase; thread -> channel position(s).
+// grid (Rp/128, 32): 128 plane rows of one phase.  Thread -> (16-byte piece of a row = 8 channel positions, row group):
+// 32 pieces x 8 row groups cover 256 positions; every thread walks 16 rows with 16-byte loads (the first version read
+// 2 bytes per lane and row, 128 dependent rounds per thread: 85 us per launch for 38 MB, twelve launches on the backward
+// chain), sums 5 x 8 accumulators and the eight row groups are combined through a wave shuffle and LDS.
 __global__ void __launch_bounds__(256) start_wgrad_kernel(const StartWgradArgs a) {
   __shared__ float4 s_a0[128];
+  __shared__ float red[4][5][256];
   const RowGeom& g = a.g;
   const int p = blockIdx.y, r0 = blockIdx.x * 128;
   if (threadIdx.x < 128) {
@@ -1242,17 +1246,52 @@ __global__ void __launch_bounds__(256) start_wgrad_kernel(const StartWgradArgs a
   }
   __syncthreads();
   const size_t slab = (size_t)p * gridDim.x + blockIdx.x;
-  for (int P = threadIdx.x; P < a.C; P += 256) {
-    const _Float16* src = a.GX + ((size_t)(P >> 6) * g.R + kRowPad + (size_t)p * g.Rp + r0) * 64 + (P & 63);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sb = 0.f;
-    for (int r = 0; r < 128; ++r) {
-      const float x = (float)src[(size_t)r * 64];
+  const int piece = threadIdx.x & 31, rg = threadIdx.x >> 5, wv = threadIdx.x >> 6;
+  for (int P0 = 0; P0 < a.C; P0 += 256) {
+    const int Pp = P0 + 8 * piece;           // first of this thread's 8 channel positions
+    const bool live = Pp < a.C;
+    const _Float16* src = a.GX + ((size_t)(Pp >> 6) * g.R + kRowPad + (size_t)p * g.Rp + r0) * 64 + (Pp & 63);
+    float acc[5][8];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = rg + 8 * i;
+      half8 x;
+      if (live) x = *(const half8*)(src + (size_t)r * 64);
+      else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = (_Float16)0.0f;
+      }
       const float4 a0 = s_a0[r];
-      s0 = fmaf(x, a0.x, s0); s1 = fmaf(x, a0.y, s1); s2 = fmaf(x, a0.z, s2); s3 = fmaf(x, a0.w, s3);
-      sb += x;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float xv = (float)x[c];
+        acc[0][c] = fmaf(xv, a0.x, acc[0][c]); acc[1][c] = fmaf(xv, a0.y, acc[1][c]);
+        acc[2][c] = fmaf(xv, a0.z, acc[2][c]); acc[3][c] = fmaf(xv, a0.w, acc[3][c]);
+        acc[4][c] += xv;
+      }
     }
+    // row groups 2w and 2w + 1 sit in the two halves of wave w
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[j][c] += __shfl_xor(acc[j][c], 32, 64);
+    if ((threadIdx.x & 32) == 0) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[wv][j][8 * piece + c] = acc[j][c];
+    }
+    __syncthreads();
     float* o = a.partial + slab * 5 * a.C;
-    o[0 * a.C + P] = s0; o[1 * a.C + P] = s1; o[2 * a.C + P] = s2; o[3 * a.C + P] = s3; o[4 * a.C + P] = sb;
+    for (int e = threadIdx.x; e < 5 * 256; e += 256) {
+      const int j = e >> 8, c = e & 255;
+      if (P0 + c < a.C) o[j * a.C + P0 + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+    }
+    __syncthreads();
   }
 }
 
