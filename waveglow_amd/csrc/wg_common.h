@@ -52,8 +52,12 @@ struct RowGeom {
                        // t >= 32 * frames[b] of utterance b are padding: never written, so they read as the zero padding
                        // of the convolutions exactly as in a batch-of-one call.  null: every utterance has L columns.
 };
+#ifdef WG_ROWPAD                 // A/B builds only
+constexpr int kRowPad = WG_ROWPAD;
+#else
 constexpr int kRowPad = 16;      // zero slack rows in front of / behind every plane chunk (taps of the first / last tile reach up to
                                  // Gf <= 16 rows past it: the guard rows of a tile read as far outside as its valid rows do)
+#endif
 constexpr int kPhases = 32;
 
 struct WnLayerArgs {
