@@ -1,15 +1,21 @@
-"""Training direction: ``WaveGlow.forward`` under autograd on the HIP library (``wg_train_forward`` / ``wg_train_backward``).
+"""Training direction: ``WaveGlow.forward`` under autograd on the HIP library.
 
 Reference: src/waveglow/model.py:178-221 (forward), train.py:190-199 (``loss.backward()``; Adam step on the
-weight-normed parameters).  Division of labour:
+weight-normed parameters).  Everything that touches a weight, an activation or a gradient runs in the library:
 
-* torch (differentiable plumbing, a few dozen small ops per step): evaluates the weight-norm parametrizations,
-  stacks the per-layer tensors, applies the kernels' channel-position permutation, folds ``WN.end`` into the skip
-  rows (``W_end @ W_skip_i``) and lays the upsample filter out per phase.  Because these ops are ordinary autograd
-  nodes, weight norm, the folds and the permutations are differentiated by torch itself.
-* the library: everything that touches activations -- upsample, 12 x (1x1 conv, start, 8 x (dilated conv + cond +
-  gate, res, skip/end), coupling) forward with saved fp16 activations, and the whole backward (both dgrads of every
-  layer, every weight gradient, coupling / 1x1 / start backward) -- one C call each way.
+* ``wg_train_prepare``: the module's own parameter tensors (weight-normed (g, v) pairs or dense weights, native layouts)
+  -> every operand of the step: weight norm, the ``WN.end`` x skip fold, channel permutations, gate pre-scale, MFMA
+  fragment orders (csrc/train_prep.hip, pack_kernel);
+* ``wg_train_forward`` / ``wg_train_backward``: upsample, 12 x (1x1 conv, start, 8 x (dilated conv + cond + gate, res,
+  skip/end), coupling) with saved fp16 activations, and the whole backward (both dgrads of every layer, every weight
+  gradient, coupling / 1x1 / start backward) -- one C call each way;
+* ``wg_train_param_grads``: packed gradients -> one gradient per parameter (weight-norm backward, the fold's chain rule) in
+  ONE flat buffer; autograd gets views of it.
+
+This file is the binding: the autograd node (``_TrainFn``), buffer allocation, the data-parallel schedule.  What is left
+to torch is ``logdet`` of the twelve 1x1 weights (model.py:63) and the optimiser.  ``pack_weights`` /
+``wn_forward_fragments`` / ``plain_fragments`` / ``to_fragments`` are the library's packing written as torch ops -- the
+checker of tests/test_gpu_train.py::test_prepare_matches_torch_packing and tests/test_host_cpu.py, not on the product path.
 
 There is no fallback: CPU tensors raise.
 """
@@ -490,7 +496,6 @@ class _TrainFn(torch.autograd.Function):
     _lib.check(lib.wg_train_param_grads(eng.handle, wts.params, wts.wn, C.byref(gstruct), _ptr(wts.aux), wts.aux.numel(),
                                         _ptr(flat), C.c_void_p(stream)))
     ctx.wts = None
-    model.last_packed_grads = bufs if os.environ.get("WG_TRAIN_KEEP_PACKED") == "1" else None      # tests
     grads = [v.view(sh) for v, sh in zip(flat.split(sizes), ctx.shapes)]
     return (None, None, None, None, None, *grads)
 
