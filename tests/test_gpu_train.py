@@ -493,3 +493,18 @@ def test_training_on_dense_weights_after_remove_weightnorm():
   loss_ref, g_ref = O.grads_ref(dense, mel, wav, oracle_cfg_from_hp(hp), 1.0)
   assert abs(float(loss.detach()) - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
   _check({n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}, g_ref, "dense")
+
+
+@pytest.mark.parametrize("channels", [64, 256])
+def test_unfused_dgrad_launches_give_the_same_gradients(channels, monkeypatch):
+  """Default: the d x launch of layer i carries d acts + the gate derivative of layer i - 1 behind it (wn_layer_kernel
+  MODE 4: the d x tile goes through LDS into the next GEMM).  WG_TRAIN_NO_FUSE=1 runs them as launches of their own (MODE 2
+  + MODE 3): same fp16 inputs to every GEMM except that the fused path feeds the d x tile to the second GEMM before it is
+  rounded through memory -- identically rounded, so the gradients agree to the last bit."""
+  over = dict(n_channels=channels, n_layers=3, n_flows=2, n_early_every=1, n_early_size=2)
+  hp, sd, mel, wav = _setup(over, 2, 9, 4, crop=40)
+  _, _, fused = _gpu_step(hp, sd, mel, wav)
+  monkeypatch.setenv("WG_TRAIN_NO_FUSE", "1")
+  _, _, plain = _gpu_step(hp, sd, mel, wav)
+  for name in fused:
+    assert torch.equal(fused[name], plain[name]), name

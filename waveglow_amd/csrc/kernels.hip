@@ -219,11 +219,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 1 && (NTAPS == 1 || NTAPS == 3), "tile geometry");
   constexpr bool Q2L = kQ2Late && DEFER && !DEEP && (NG + NT - 1) / NT == 1 && NT >= NG + MT;   // free slots behind the DMA pieces
   static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && ((NKX >= 4 && NKX % 2 == 0) || NKX == 3)), "deep prefetch variant");
-  static_assert(MODE == 0 || (TPW == 1 && CX == (MODE == 2 ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
+  static_assert(MODE == 0 || (TPW == 1 && CX == ((MODE == 2 || MODE == 4) ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sB = smem;                     // 2 x BT_BYTES
-  char* const sActs = smem + 2 * BT_BYTES;   // BN x ACT_ROW
+  char* const sActs = MODE == 4 ? smem : smem + 2 * BT_BYTES;   // BN x ACT_ROW (MODE 4: over the B tiles, after the K loop --
+                                                                  // 66 KB per workgroup keeps two workgroups on a CU)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,45 +707,134 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       // ---- backward dgrad epilogues: lane (column n = ln of N tile nt, half h) holds rows (= storage positions)
       // [32 blk + 16 h, +16) of its column, 32 contiguous bytes of every fp16 plane.  Only real columns are written:
       // rows of padding columns stay zero (cleared once per workspace geometry), the weight-gradient kernels sum over them.
+      // gate derivative (model.py:17-19): d u = g S (1 - T^2), d v = g T S (1 - S) -> the 2C d-pre planes
+      auto gate_derivative = [&](const f32x16& g, const _Float16* tp, const _Float16* sp_, _Float16* dst, size_t off) {
+        const half8 t0 = *(const half8*)(tp + off), t1 = *(const half8*)(tp + off + 8);
+        const half8 s0 = *(const half8*)(sp_ + off), s1 = *(const half8*)(sp_ + off + 8);
+        half8 o0, o1, p0, p1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float ta = (float)t0[r], sa = (float)s0[r], ga = g[r];
+          const float tb = (float)t1[r], sb = (float)s1[r], gb = g[8 + r];
+          o0[r] = (_Float16)(ga * sa * (1.0f - ta * ta));
+          o1[r] = (_Float16)(gb * sb * (1.0f - tb * tb));
+          p0[r] = (_Float16)(ga * ta * sa * (1.0f - sa));
+          p1[r] = (_Float16)(gb * tb * sb * (1.0f - sb));
+        }
+        const size_t off_s = off + (size_t)(C / 64) * R * 64;      // the sigmoid half: chunks C/64 .. 2C/64-1
+        *(half8*)(dst + off) = o0;
+        *(half8*)(dst + off + 8) = o1;
+        *(half8*)(dst + off_s) = p0;
+        *(half8*)(dst + off_s + 8) = p1;
+      };
+      int lno = ln, lho = lh;
+      if constexpr (MODE == 4) {
+        asm volatile("" : "+v"(lno), "+v"(lho));
+        __syncthreads();            // every wave is through its last B-tile reads: the d x tile goes over the B tiles in LDS
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         int cb, ct;
-        if (!column_of(rr0 + nt * 32 + ln, p, cb, ct)) continue;
+        const bool col_ok = column_of(rr0 + nt * 32 + ln, p, cb, ct);
+        if (MODE != 4 && !col_ok) continue;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const int blk = wave * MB + mb;
           const size_t off = ((size_t)(blk >> 1) * R + r0 + nt * 32 + ln) * 64 + (blk & 1) * 32 + lh * 16;
-          half8 o0, o1;
-          if constexpr (MODE == 2) {
+          if constexpr (MODE == 2 || MODE == 4) {
             // d x_i = d x_{i+1} (residual path, model.py:131-132) + the three taps' contributions
-            half8 i0, i1;
+            half8 i0, i1, o0, o1;
             if (a.in0) { i0 = *(const half8*)(a.in0 + off); i1 = *(const half8*)(a.in0 + off + 8); }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               o0[r] = (_Float16)(acc[mb][nt][r] + (a.in0 ? (float)i0[r] : 0.0f));
               o1[r] = (_Float16)(acc[mb][nt][8 + r] + (a.in0 ? (float)i1[r] : 0.0f));
             }
-            *(half8*)(a.out0 + off) = o0;
-            *(half8*)(a.out0 + off + 8) = o1;
-          } else {
-            // gate derivative (model.py:17-19): d u = g S (1 - T^2), d v = g T S (1 - S) -> the 2C d-pre planes
-            const half8 t0 = *(const half8*)(a.in0 + off), t1 = *(const half8*)(a.in0 + off + 8);
-            const half8 s0 = *(const half8*)(a.in1 + off), s1 = *(const half8*)(a.in1 + off + 8);
-            half8 p0, p1;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-              const float ta = (float)t0[r], sa = (float)s0[r], ga = acc[mb][nt][r];
-              const float tb = (float)t1[r], sb = (float)s1[r], gb = acc[mb][nt][8 + r];
-              o0[r] = (_Float16)(ga * sa * (1.0f - ta * ta));
-              o1[r] = (_Float16)(gb * sb * (1.0f - tb * tb));
-              p0[r] = (_Float16)(ga * ta * sa * (1.0f - sa));
-              p1[r] = (_Float16)(gb * tb * sb * (1.0f - sb));
+            if (col_ok) {
+              *(half8*)(a.out0 + off) = o0;
+              *(half8*)(a.out0 + off + 8) = o1;
             }
-            const size_t off_s = off + (size_t)(C / 64) * R * 64;      // the sigmoid half: chunks C/64 .. 2C/64-1
-            *(half8*)(a.out0 + off) = o0;
-            *(half8*)(a.out0 + off + 8) = o1;
-            *(half8*)(a.out0 + off_s) = p0;
-            *(half8*)(a.out0 + off_s + 8) = p1;
+            if constexpr (MODE == 4) {
+              // ... and into LDS as the B operand of the next GEMM (fp16, position-major rows like the forward's acts tile;
+              // padding columns: zeros, as the planes hold them)
+              if (!col_ok) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { o0[r] = (_Float16)0.0f; o1[r] = (_Float16)0.0f; }
+              }
+              char* ap = sActs + lno * ACT_ROW + lho * 32 + nt * 32 * ACT_ROW + blk * 64;
+              *(half8*)(ap) = o0;
+              *(half8*)(ap + 16) = o1;
+            }
+          } else {
+            gate_derivative(acc[mb][nt], a.in0, a.in1, a.out0, off);
+          }
+        }
+      }
+      if constexpr (MODE == 4) {
+        // ---- fused: d acts_{i-1} = W_res_{i-1}^T d x_i + (W_end W_skip_{i-1})^T d out  on the tile just computed (it would
+        // otherwise be written, and read back by a launch of its own: wn_layer_kernel MODE 3), then the gate derivative
+        // -> d pre_{i-1}.  A fragments straight from the K-loop layout of `wat` ([K-step][half][wave][mb][k16 & 1][64][8]):
+        // k16 step k of the d x part sits at K-step k >> 2, half (k >> 1) & 1, k & 1; the d out plane's 16 live positions
+        // are k16 step 0 of K-step C/64.
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int KX = C / 16;                             // k16 steps over the d x tile
+        auto a_frag = [&](int mb, int k) -> half8 {
+          const size_t e = ((((size_t)(k >> 2) * 2 + ((k >> 1) & 1)) * NW + wave) * MB + mb) * 2 + (k & 1);
+          return *((const half8*)a.wat_prev + e * 64 + lane);
+        };
+        f32x16 acc2[MB][NT];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[mb][nt][j] = 0.0f;
+        constexpr int PF4 = 4;
+        half8 af[MB][PF4];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int i = 0; i < PF4; ++i) af[mb][i] = a_frag(mb, i);
+        // d out fragments (k16 step 0 of the d out plane): positions 8 lh .. 8 lh + 7 of this lane's columns
+        half8 go[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) go[nt] = *(const half8*)(a.gout + ((size_t)r0 + nt * 32 + lno) * 64 + lho * 8);
+        const char* const acts_rd = sActs + lno * ACT_ROW + lho * 16;
+        half8 bq[2][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *(const half8*)(acts_rd + nt * 32 * ACT_ROW);
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+          if (k + 1 < KX) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[(k + 1) & 1][nt] = *(const half8*)(acts_rd + nt * 32 * ACT_ROW + (k + 1) * 32);
+          }
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const half8 afk = af[mb][k % PF4];
+            if (k + PF4 < KX) af[mb][k % PF4] = a_frag(mb, k + PF4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc2[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afk, bq[k & 1][nt], acc2[mb][nt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const half8 afo = a_frag(mb, 4 * (C / 64));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc2[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afo, go[nt], acc2[mb][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          int cb, ct;
+          if (!column_of(rr0 + nt * 32 + lno, p, cb, ct)) continue;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int blk = wave * MB + mb;
+            const size_t off = ((size_t)(blk >> 1) * R + r0 + nt * 32 + lno) * 64 + (blk & 1) * 32 + lho * 16;
+            gate_derivative(acc2[mb][nt], a.t_prev, a.s_prev, a.dpre_prev, off);
           }
         }
       }
@@ -1144,7 +1234,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
-  constexpr int smem = 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
+  constexpr int smem = MODE == 4 ? (BN * (2 * C + 16) > 2 * BN * 128 ? BN * (2 * C + 16) : 2 * BN * 128)
+                                 : 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
   int cur_dev = 0;
   if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
@@ -1232,25 +1323,29 @@ hipError_t launch_wn_layer_train(const WnLayerArgs& a, int C, int bn, hipStream_
 }
 
 // backward dgrad GEMMs on the WN-layer K loop.  kind 2: d x (3 taps over the 2C d-pre planes); kind 3: d acts + gate
-// derivative (a.x_tap = d x planes + a.sp = d out plane, or -- a.x_tap == a.sp's plane alone -- the last layer of a flow)
+// derivative (a.x_tap = d x planes + a.sp = d out plane, or -- a.x_tap == a.sp's plane alone -- the last layer of a flow);
+// kind 4: kind 2 of layer i with kind 3 of layer i-1 fused behind it (wat_prev, gout, t_prev, s_prev, dpre_prev)
 template <int C>
 static hipError_t launch_wn_plain_t(const WnLayerArgs& a, int kind, int bn, hipStream_t s) {
   constexpr int CCH = C / 64;
   if constexpr (WnCfg<C>::BN == 128) {
     if (bn == 128) {
       if (kind == 2) return launch_wn_tttt<C, 128, false, 1, 2 * CCH, 2, 3, false>(a, s);
+      if (kind == 4) return launch_wn_tttt<C, 128, false, 1, 2 * CCH, 4, 3, false>(a, s);
       if (a.x_chunks_per_tap == 1 && a.n_cond_steps == 0) return launch_wn_tttt<C, 128, false, 1, 1, 3, 1, false>(a, s);
       return launch_wn_tttt<C, 128, false, 1, CCH, 3, 1, true>(a, s);
     }
   }
   if (bn != 64) return hipErrorInvalidValue;
   if (kind == 2) return launch_wn_tttt<C, 64, false, 1, 2 * CCH, 2, 3, false>(a, s);
+  if (kind == 4) return launch_wn_tttt<C, 64, false, 1, 2 * CCH, 4, 3, false>(a, s);
   if (a.x_chunks_per_tap == 1 && a.n_cond_steps == 0) return launch_wn_tttt<C, 64, false, 1, 1, 3, 1, false>(a, s);
   return launch_wn_tttt<C, 64, false, 1, CCH, 3, 1, true>(a, s);
 }
 hipError_t launch_wn_plain(const WnLayerArgs& a, int C, int kind, int bn, hipStream_t s) {
-  if ((kind != 2 && kind != 3) || !a.out0 || !a.x_tap || (kind == 3 && (!a.in0 || !a.in1))) return hipErrorInvalidValue;
-  if (kind == 2 && (a.x_chunks_per_tap != 2 * (C / 64) || a.n_cond_steps != 0)) return hipErrorInvalidValue;
+  if ((kind != 2 && kind != 3 && kind != 4) || !a.out0 || !a.x_tap || (kind == 3 && (!a.in0 || !a.in1))) return hipErrorInvalidValue;
+  if ((kind == 2 || kind == 4) && (a.x_chunks_per_tap != 2 * (C / 64) || a.n_cond_steps != 0)) return hipErrorInvalidValue;
+  if (kind == 4 && (!a.wat_prev || !a.gout || !a.t_prev || !a.s_prev || !a.dpre_prev)) return hipErrorInvalidValue;
   if (kind == 3 && !((a.x_chunks_per_tap == 1 && a.n_cond_steps == 0) || (a.x_chunks_per_tap == C / 64 && a.n_cond_steps == 1 && a.sp)))
     return hipErrorInvalidValue;
   switch (C) {

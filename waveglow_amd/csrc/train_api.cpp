@@ -495,6 +495,8 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
     if (!(sR = wg_internal_aux_stream(h, 2))) return wg_set_error(WG_ERR_HIP, "cannot create the slab-reduction stream");
   }
   const int* const n_slabs = x.n_slabs;
+  bool fuse = true;                       // WG_TRAIN_NO_FUSE=1 (tests, A/B): d acts + gate derivative as launches of their own
+  if (const char* e = getenv("WG_TRAIN_NO_FUSE")) fuse = !(*e == '1');
   int BNw = wn_block_n(C);
   if (BNw == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)n_cu) BNw = 64;
   if (const char* e = getenv("WG_FORCE_BN")) {
@@ -577,7 +579,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
       const _Float16* Xi = w.X + (size_t)fl * w.plane_c;
       const _Float16* Ai = w.A + (size_t)fl * w.plane_c;
       _Float16* GPi = w.GP + (size_t)fl * 2 * w.plane_c;
-      {
+      // Fused (round 3): the d x launch of layer i + 1 has already produced d pre of this layer behind its own result
+      // (wn_layer_kernel MODE 4: the d x tile goes through LDS into the next GEMM instead of out to the planes and back in
+      // through a launch of its own); only a flow's last layer, which has no d x above it, runs MODE 3 alone.
+      if (!fuse || i == nl - 1) {
         // d acts = W_res^T d x_{i+1} + (W_end W_skip_i)^T d out ; gate derivative -> d pre   (wn_layer_kernel MODE 3)
         WnLayerArgs a;
         memset(&a, 0, sizeof a);
@@ -607,10 +612,10 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
           hipStream_t sh = half ? sB : s;
           TR_PROF(sh, 5, TR_TRY(launch_part(a, g, BNw, half, bh, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 3, bn, sh); })));
         }
-        // the weight-gradient stream continues once both chains have written their half of d pre (and of d x_{i+1} before it)
-        TR_ORDER(order_after(h, s, sW));
-        TR_ORDER(order_after(h, sB, sW));
       }
+      // the weight-gradient stream continues once both chains have written their half of d pre (and of d x_{i+1} before it)
+      TR_ORDER(order_after(h, s, sW));
+      TR_ORDER(order_after(h, sB, sW));
       {
         // d W1 = d pre x [x taps | spect]^T, d b1;
         // d W2 = d x_{i+1} x acts^T, d b2  and  d (W_end W_skip_i) = d out x acts^T  share the X operand (acts): one
@@ -688,10 +693,18 @@ int wg_train_backward_flows(wg_handle* h, const wg_train_weights* wt, const wg_t
         a.in0 = gx;
         _Float16* const gxi = w.GXL + (size_t)i * w.plane_c;
         a.out0 = gxi;
+        const int kind = (fuse && i > 0) ? 4 : 2;
+        if (kind == 4) {      // ... and d acts + gate derivative of layer i - 1 on the tile (see above)
+          a.wat_prev = wat + (size_t)(fl - 1) * wat_n;
+          a.gout = GOk;
+          a.t_prev = w.T + (size_t)(fl - 1) * w.plane_c;
+          a.s_prev = w.S + (size_t)(fl - 1) * w.plane_c;
+          a.dpre_prev = w.GP + (size_t)(fl - 1) * 2 * w.plane_c;
+        }
         for (int half = 0; half < bh; ++half) {
           hipStream_t sh = half ? sB : s;
           if (i > 0) TR_ORDER(wait_for(sh, w_done[i - 1]));     // the previous flow's reader of GXL[i] (not yet re-marked: layer i-1 of this flow comes later)
-          TR_PROF(sh, 5, TR_TRY(launch_part(a, g, BNw, half, bh, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, 2, bn, sh); })));
+          TR_PROF(sh, 5, TR_TRY(launch_part(a, g, BNw, half, bh, [&](const WnLayerArgs& q, int bn) { return launch_wn_plain(q, C, kind, bn, sh); })));
         }
         gx = gxi;
       }

@@ -244,6 +244,29 @@ __global__ void __launch_bounds__(256) wn_grad_kernel(const PrepArgs a) {
     }
     return src[(size_t)x * C + q.row];       // dstart [5][C]: column j of the start weight
   };
+  // one pass over dW and v: the row (<= 12 elements per lane up to 768 columns) stays in registers between the dot product
+  // and the write (longer rows -- 512 channels x 3 taps -- take the two-pass form)
+  constexpr int kKeep = 12;
+  if (q.len <= 64 * kKeep) {
+    float dw[kKeep], vv[kKeep];
+    float dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) {
+      const int x = lane + 64 * j;
+      dw[j] = x < q.len ? dW(x) : 0.0f;
+      vv[j] = (normed && x < q.len) ? v[x] : 0.0f;
+      dot += dw[j] * vv[j];
+    }
+    dot = wave_sum(dot);
+    const float coef = s * dot * inv * inv;
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) {
+      const int x = lane + 64 * j;
+      if (x < q.len) dv[x] = normed ? s * dw[j] - coef * vv[j] : dw[j];
+    }
+    if (normed && lane == 0) a.flat[a.goff[prep_slot(a, sv + 1, q.mod)] + q.row] = dot * inv;
+    return;
+  }
   float dot = 0.0f;
   if (normed)
     for (int x = lane; x < q.len; x += 64) dot += dW(x) * v[x];

@@ -97,6 +97,12 @@ struct WnLayerArgs {
   const _Float16* in0;      // MODE 2: d x_{i+1} planes added to the result (or null); MODE 3: saved tanh planes
   const _Float16* in1;      // MODE 3: saved sigmoid planes
   _Float16* out0;           // MODE 2: d x_i planes [C/64]; MODE 3: d pre planes [2C/64] (tanh half, then sigmoid half)
+  // ---- MODE 4 = MODE 2 of layer i fused with MODE 3 of layer i-1 (the d x_i tile never leaves the workgroup between them):
+  const _Float16* wat_prev; // plain-row-block fragments [W_res^T | (W_end W_skip)^T] of layer i-1 (wg_train_weights::wat)
+  const _Float16* gout;     // the flow's d out plane [1][R][64]
+  const _Float16* t_prev;   // saved tanh / sigmoid planes of layer i-1
+  const _Float16* s_prev;
+  _Float16* dpre_prev;      // d pre planes [2C/64] of layer i-1
 };
 
 struct MelPackArgs {
