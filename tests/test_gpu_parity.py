@@ -656,18 +656,20 @@ def test_synthesizer_against_oracle_composition(tmp_path, strength):
                                   dict(n_channels=384, n_layers=2, n_flows=2, n_early_every=1, n_early_size=2),
                                   dict(n_channels=30, n_layers=4, n_flows=4, n_early_every=2),
                                   dict(n_channels=64, n_layers=9, n_flows=2, n_early_every=1, n_early_size=2),
-                                  dict(n_channels=128, n_layers=10, n_flows=2, n_early_every=1, n_early_size=2)],
-                         ids=["c96", "c384", "c30", "l9", "l10"])
+                                  dict(n_channels=128, n_layers=10, n_flows=2, n_early_every=1, n_early_size=2),
+                                  dict(n_channels=64, n_mel_channels=24, n_layers=3, n_flows=4, n_early_every=2),
+                                  dict(n_channels=96, n_mel_channels=72, n_layers=2, n_flows=2, n_early_every=1, n_early_size=2)],
+                         ids=["c96", "c384", "c30", "l9", "l10", "m24", "c96m72"])
 def test_hparam_envelope_channels_and_layers(over):
-  """The reference takes any even n_channels and any n_layers (model.py:75-113, hparams.py:19-31).  Widths between the
-  instantiated ones run zero-padded (exact); 9 and 10 layers (dilations 256, 512) need 8 / 16 guard frames per utterance
-  instead of 4.  infer and the no-grad forward against the CPU oracle, two utterances long enough for the largest
+  """The reference takes any even n_channels, any n_layers and any n_mel_channels (model.py:75-113, :141-150,
+  hparams.py:19-31).  Widths between the instantiated ones and mel counts that are not multiples of 16 run zero-padded
+  (exact); 9 and 10 layers (dilations 256, 512) need 8 / 16 guard frames per utterance instead of 4.  infer and the no-grad forward against the CPU oracle, two utterances long enough for the largest
   dilation to reach real samples on both sides."""
   from oracle import torch_oracle as O
   hp = HParams(**over)
   sd = synthetic.make_state_dict(hp, seed=17)
   B, T, sigma = 2, 40, 0.8
-  mel = synthetic.make_mel(B, T, seed=9)
+  mel = synthetic.make_mel(B, T, seed=9)[:, :hp.n_mel_channels].contiguous()
   z_init, z_early = synthetic.make_noise(hp, B, 32 * T, seed=5)
   model = build_model(hp, sd)
   out = gpu_infer(model, mel, z_init, z_early, sigma)

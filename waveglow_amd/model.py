@@ -81,7 +81,13 @@ class _Engine:
     if not self.width or hp.n_channels < 1:
       raise _lib.WgError(f"n_channels={hp.n_channels} unsupported (1..512)")
     self.n_layers = hp.n_layers
-    cfg = _lib.WgConfig(hp.n_mel_channels, hp.n_flows, hp.n_group, hp.n_early_every, hp.n_early_size,
+    # the same for the mel axis: the conditioning K-steps take multiples of 16 mel channels (<= 80); other counts run with
+    # zero filter taps / conditioning columns for the extra channels and a zero-padded input
+    self.n_mel = hp.n_mel_channels
+    self.mel_width = (hp.n_mel_channels + 15) // 16 * 16
+    if not 1 <= hp.n_mel_channels <= 80:
+      raise _lib.WgError(f"n_mel_channels={hp.n_mel_channels} unsupported (1..80)")
+    cfg = _lib.WgConfig(self.mel_width, hp.n_flows, hp.n_group, hp.n_early_every, hp.n_early_size,
                         hp.n_layers, self.width, hp.kernel_size, 1024, 256)
     handle = C.c_void_p()
     _lib.check(lib.wg_create(C.byref(cfg), _lib.device_index(device), C.byref(handle)))
@@ -111,6 +117,8 @@ class _Engine:
       t = tensors[name].detach().to(device="cpu", dtype=torch.float32)
       if self.width != self.n_channels:
         t = self._pad_channels(name, t)
+      if self.mel_width != self.n_mel:
+        t = self._pad_mel(name, t)
       t = t.contiguous()
       shape = (C.c_int64 * t.dim())(*t.shape)
       _lib.check(self.lib.wg_set_tensor(self.handle, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
@@ -143,6 +151,24 @@ class _Engine:
       t = halves(t, t.shape[0] // Cc)
       return pad(t, (0, 0, 0, W - Cc)) if leaf == "weight" else t
     return t
+
+  def _pad_mel(self, name: str, t: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the mel axes from n_mel_channels to the next multiple of 16: upsample [M, M, 1024] / [M], and the input
+    axis of cond_layer [.., 8 M, 1], whose columns are mel-major (column = mel * 8 + g: the padding is a tail)."""
+    pad = torch.nn.functional.pad
+    d = self.mel_width - self.n_mel
+    if name == "upsample.weight":
+      return pad(t, (0, 0, 0, d, 0, d))
+    if name == "upsample.bias":
+      return pad(t, (0, d))
+    if name.endswith("cond_layer.weight"):
+      return pad(t, (0, 0, 0, 8 * d))
+    return t
+
+  def pad_mel_input(self, spect: torch.Tensor) -> torch.Tensor:
+    if self.mel_width == self.n_mel:
+      return spect
+    return torch.nn.functional.pad(spect, (0, 0, 0, self.mel_width - self.n_mel))
 
   def workspace(self, kind: str, nbytes: int, key: Tuple[int, int, int]) -> torch.Tensor:
     """One cached workspace (the last shape's).  A captured hipGraph bakes its workspace's device pointer in, so
@@ -266,7 +292,7 @@ class WaveGlow(nn.Module):
       return self._infer_graphed(spect, z_init, z_early, sigma, frames)
     eng = self._get_engine(spect.device)
     io = self._io_dtype(spect)
-    spect = spect.contiguous()
+    spect = eng.pad_mel_input(spect).contiguous()
     B, M, T = spect.shape
     L = T * 256 // self.n_group
     assert z_init.shape == (B, self.n_remaining_channels, L) and z_init.dtype == spect.dtype
@@ -349,7 +375,7 @@ class WaveGlow(nn.Module):
     eng = self._get_engine(spect.device)
     io = self._io_dtype(spect)
     assert audio.dtype == spect.dtype and audio.device == spect.device
-    spect, audio = spect.contiguous(), audio.contiguous()
+    spect, audio = eng.pad_mel_input(spect).contiguous(), audio.contiguous()
     B, M, F_ = spect.shape
     S = audio.shape[1]
     assert (F_ - 1) * 256 + 1024 >= S   # model.py:187

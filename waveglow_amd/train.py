@@ -519,9 +519,10 @@ def train_forward(model, mel: torch.Tensor, audio: torch.Tensor, grad_scale: flo
   audio = audio[:, :S].contiguous()
   mel = mel.contiguous()
   eng = model._get_engine(mel.device, need_weights=False)
-  if eng.width != eng.n_channels:
-    raise _lib.WgError(f"n_channels={eng.n_channels}: the training direction takes the kernel widths {eng.KERNEL_WIDTHS} only "
-                       "(inference and the no-grad forward zero-pad other widths)")
+  if eng.width != eng.n_channels or eng.mel_width != eng.n_mel:
+    raise _lib.WgError(f"n_channels={eng.n_channels}, n_mel_channels={eng.n_mel}: the training direction takes the kernel widths "
+                       f"{eng.KERNEL_WIDTHS} and mel counts that are multiples of 16 only (inference and the no-grad forward "
+                       "zero-pad the others)")
   _names, tensors, wn = canonical_params(model, eng)
   out = _TrainFn.apply(model, mel, audio, grad_scale, wn, *tensors)
   z, log_s = out[0], list(out[1:])
