@@ -132,6 +132,13 @@ struct wg_handle {
   // their own, one event per role, so that no number of ring events consumed in between can re-record one under a wait
   hipEvent_t mark_ev[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // pinned staging buffers for small host -> device table uploads (wg_train_prepare / wg_train_param_grads): a rotating set,
+  // each guarded by an event recorded behind its copy, so a buffer is never rewritten while a copy out of it is pending
+  static constexpr int kPins = 4;
+  void* pin[kPins] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pin_bytes[kPins] = {0, 0, 0, 0};
+  hipEvent_t pin_ev[kPins] = {nullptr, nullptr, nullptr, nullptr};
+  int pin_next = 0;
 };
 
 namespace {
@@ -263,6 +270,27 @@ hipStream_t wg_internal_aux_stream(wg_handle* h, int i) {
   }
   return h->aux[i];
 }
+// Copies `bytes` of host memory to `dst` (device) on stream `s` through a pinned staging buffer of the handle: the caller's
+// source may be freed or rewritten as soon as this returns, and the copy itself is asynchronous.
+hipError_t wg_internal_upload(wg_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (!h) return hipErrorInvalidValue;
+  const int i = h->pin_next;
+  h->pin_next = (i + 1) % wg_handle::kPins;
+  hipError_t e;
+  if (h->pin_ev[i] && (e = hipEventSynchronize(h->pin_ev[i])) != hipSuccess) return e;     // its last copy has run
+  if (h->pin_bytes[i] < bytes) {
+    if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+    h->pin[i] = nullptr;
+    h->pin_bytes[i] = 0;
+    const size_t cap = bytes < 65536 ? 65536 : bytes;
+    if ((e = hipHostMalloc(&h->pin[i], cap, hipHostMallocDefault)) != hipSuccess) return e;
+    h->pin_bytes[i] = cap;
+  }
+  if (!h->pin_ev[i] && (e = hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+  memcpy(h->pin[i], src, bytes);
+  if ((e = hipMemcpyAsync(dst, h->pin[i], bytes, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+  return hipEventRecord(h->pin_ev[i], s);
+}
 // Event `slot` of the mark pool (no timing), created on first use.
 hipEvent_t wg_internal_mark_event(wg_handle* h, int slot) {
   if (!h || slot < 0 || slot >= 16) return nullptr;
@@ -348,6 +376,10 @@ int wg_destroy(wg_handle* h) {
   for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
   for (hipEvent_t e : h->mark_ev)
     if (e) hipEventDestroy(e);
+  for (int i = 0; i < wg_handle::kPins; ++i) {
+    if (h->pin_ev[i]) hipEventDestroy(h->pin_ev[i]);
+    if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+  }
   for (hipStream_t st : h->aux)
     if (st) hipStreamDestroy(st);
   delete h;

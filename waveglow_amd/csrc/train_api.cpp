@@ -21,6 +21,7 @@ void wg_internal_prof_event(wg_handle* h, void* stream, int cls);         // api
 hipStream_t wg_internal_aux_stream(wg_handle* h, int i);                  // api.cpp
 hipEvent_t wg_internal_sync_event(wg_handle* h);                          // api.cpp
 hipEvent_t wg_internal_mark_event(wg_handle* h, int slot);                // api.cpp
+hipError_t wg_internal_upload(wg_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s);   // api.cpp
 int wg_internal_n_cu(const wg_handle* h);                                 // api.cpp
 
 namespace {
@@ -899,8 +900,9 @@ int prep_args(wg_handle* h, const void* const* params, int weight_normed, const 
     }
   }
   char* base = (char*)aux;
-  TR_TRY(hipMemcpyAsync(base + L.tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
-  TR_TRY(hipMemcpyAsync(base + L.goff, goff.data(), goff.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  // (through the handle's pinned staging buffers: `tab` / `goff` die with this call, the copies run later on the stream)
+  TR_TRY(wg_internal_upload(h, base + L.tab, tab.data(), tab.size() * sizeof(void*), s));
+  TR_TRY(wg_internal_upload(h, base + L.goff, goff.data(), goff.size() * sizeof(long long), s));
   memset(&a, 0, sizeof a);
   a.tab = (void* const*)(base + L.tab);
   a.goff = (const long long*)(base + L.goff);
