@@ -88,6 +88,7 @@ constexpr float kSigmScale = -1.4426950408889634f;   // -log2(e)
 struct LayerOffsets {
   size_t wA1, bias1, wA2, bias2, wEs;
   size_t wA1f = 0;   // layer 0 only: in_layers[0] o start folded onto the a0 plane, 3 K-steps
+  size_t wA1x = 0, wA1fx = 0;   // the same two as 16x16x32 fragments (wn_frag16: the 128-column tile's K loop)
 };
 struct FlowOffsets {
   std::vector<LayerOffsets> layers;
@@ -109,6 +110,7 @@ struct wg_handle {
   char* d_blob = nullptr;
   size_t blob_bytes = 0;
   char* d_cond = nullptr;   // derived: folded cond_layer o upsample A fragments [flow][layer][phase]...
+  char* d_cond16 = nullptr; // ... as 16x16x32 fragments (wn_frag16), same sizes
   size_t cond_layer_bytes = 0, cond_flow_bytes = 0;
   std::vector<FlowOffsets> flows;
   int n_cu = 256;         // multiProcessorCount, read in wg_finalize
@@ -372,6 +374,7 @@ int wg_destroy(wg_handle* h) {
   if (!h) return WG_OK;
   if (h->d_blob) hipFree(h->d_blob);
   if (h->d_cond) hipFree(h->d_cond);
+  if (h->d_cond16) hipFree(h->d_cond16);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
   for (hipEvent_t e : h->mark_ev)
@@ -522,6 +525,28 @@ int wg_finalize(wg_handle* h) {
                   }
                 }
       }
+      const bool f16 = wn_frag16(C, wn_block_n(C));
+      // 16x16x32 fragments [half K-step u][wave][tile m][64 lanes = (row i = lane & 15, K group lane >> 4)][8]: tile m of
+      // wave w = rows 32 w + 16 (m & 1) + i of the tanh (m < 2) / sigmoid half; K = 32 (u & 1) + 8 (lane >> 4) + j of the step
+      auto pack16 = [&](size_t off, int n_half, auto&& value) {
+        _Float16* dst = (_Float16*)(blob.data() + off);
+        for (int u = 0; u < n_half; ++u)
+          for (int w = 0; w < NW; ++w)
+            for (int m4 = 0; m4 < 4; ++m4)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int m = (m4 < 2 ? 0 : C) + 32 * w + 16 * (m4 & 1) + (lane & 15);
+                const float rs = m4 < 2 ? kTanhScale : kSigmScale;
+                _Float16* d = dst + ((((size_t)u * NW + w) * 4 + m4) * 64 + lane) * 8;
+                for (int j = 0; j < 8; ++j) d[j] = (_Float16)(value(m, u >> 1, 32 * (u & 1) + 8 * (lane >> 4) + j) * rs);
+              }
+      };
+      if (f16) {
+        lo.wA1x = reserve((size_t)nKx * 2 * NW * 4 * 64 * 8 * 2);
+        pack16(lo.wA1x, 2 * nKx, [&](int m, int ksx, int kk) {
+          const int tap = ksx / CC, cc = ksx % CC;
+          return win->data[((size_t)m * C + pos_to_chan(cc * 64 + kk)) * 3 + tap];
+        });
+      }
       if (i == 0) {
         // in_layers[0] o start (model.py:117, :123): column kk of tap `tap` on the a0 plane row (a0 | 1 | 0...):
         //   kk < h: sum_ch W_in[m][ch][tap] W_start[ch][kk];  kk == 4: sum_ch W_in[m][ch][tap] b_start[ch]
@@ -553,6 +578,10 @@ int wg_finalize(wg_handle* h) {
                     d[j] = (_Float16)(kk < 8 ? (float)(fold[((size_t)m * 3 + tap) * 8 + kk] * rs) : 0.0f);
                   }
                 }
+        if (f16) {
+          lo.wA1fx = reserve((size_t)3 * 2 * NW * 4 * 64 * 8 * 2);
+          pack16(lo.wA1fx, 2 * 3, [&](int m, int tap, int kk) { return kk < 8 ? (float)fold[((size_t)m * 3 + tap) * 8 + kk] : 0.0f; });
+        }
       }
       lo.bias1 = reserve((size_t)2 * C * 4);
       {
@@ -648,6 +677,11 @@ int wg_finalize(wg_handle* h) {
     h->cond_layer_bytes = (size_t)kPhases * n_half * NW * MT * 2 * 64 * 8 * 2;
     h->cond_flow_bytes = h->cond_layer_bytes * NL;
     HIP_TRY(hipMalloc((void**)&h->d_cond, h->cond_flow_bytes * c.n_flows));
+    if (h->d_cond16) {
+      HIP_TRY(hipFree(h->d_cond16));
+      h->d_cond16 = nullptr;
+    }
+    if (wn_frag16(C, wn_block_n(C))) HIP_TRY(hipMalloc((void**)&h->d_cond16, h->cond_flow_bytes * c.n_flows));
     float *d_wc = nullptr, *d_up = nullptr;
     const size_t wc_bytes = (size_t)2 * C * NL * NS * 4, up_bytes = (size_t)M * M * c.upsample_kernel * 4;
     HIP_TRY(hipMalloc((void**)&d_wc, wc_bytes));
@@ -657,7 +691,10 @@ int wg_finalize(wg_handle* h) {
       const HostTensor* wcond = find(h, "WN." + std::to_string(k) + ".cond_layer.weight");
       HIP_TRY(hipMemcpy(d_wc, wcond->data.data(), wc_bytes, hipMemcpyHostToDevice));
       HIP_TRY(launch_cond_fold(d_wc, d_up, (_Float16*)(h->d_cond + h->cond_flow_bytes * k), C, NW, M, NL,
-                               c.upsample_kernel, kTanhScale, kSigmScale, nullptr));
+                               c.upsample_kernel, kTanhScale, kSigmScale, 0, nullptr));
+      if (h->d_cond16)
+        HIP_TRY(launch_cond_fold(d_wc, d_up, (_Float16*)(h->d_cond16 + h->cond_flow_bytes * k), C, NW, M, NL,
+                                 c.upsample_kernel, kTanhScale, kSigmScale, 1, nullptr));
       HIP_TRY(hipDeviceSynchronize());
       if (dbg_sync()) { fprintf(stderr, "[wg] cond_fold flow %d ok\n", k); fflush(stderr); }
     }
@@ -699,8 +736,9 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.x_tap = fold0 ? w.A0 : cur;
     a.x_chunks_per_tap = fold0 ? 1 : C / 64;
     a.melT = w.melT;
-    a.wA1c = (const _Float16*)(h->d_cond + h->cond_flow_bytes * k + h->cond_layer_bytes * i);
-    a.wA1 = (const _Float16*)(h->d_blob + (fold0 ? lo.wA1f : lo.wA1));
+    a.frag16 = wn_frag16(C, BN) ? 1 : 0;
+    a.wA1c = (const _Float16*)((a.frag16 ? h->d_cond16 : h->d_cond) + h->cond_flow_bytes * k + h->cond_layer_bytes * i);
+    a.wA1 = (const _Float16*)(h->d_blob + (a.frag16 ? (fold0 ? lo.wA1fx : lo.wA1x) : (fold0 ? lo.wA1f : lo.wA1)));
     a.bias1 = (const float*)(h->d_blob + lo.bias1);
     a.wA2 = (const _Float16*)(h->d_blob + lo.wA2);
     a.bias2 = (const float*)(h->d_blob + lo.bias2);

@@ -199,7 +199,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // removed).  Two rings Q[parity of the step][quarter]; the quarter consumed in sub-step g of step ks is reloaded with the
 // fragment of step ks + 2.  Every fragment a step needs was issued more than a step earlier, so the step's only wait is
 // the counted one in front of its barrier.  The steps are written out for nK = NKX + 5 (80 mel channels).
-template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false>
+template <int C, int NW, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false, bool M16 = false>
 __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) {
   constexpr bool TR = MODE == 1;         // training forward
   constexpr bool PLAIN = MODE >= 2;      // backward dgrad GEMMs
@@ -217,7 +217,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   constexpr int NAH = MT * 2;            // A fragments per half K-step (packing unit)
   constexpr bool DEFER = (MB == 1);      // defer a step's last sub-step past the barrier (needs spare registers)
   static_assert(BN * 8 % NTHREADS == 0 && MB >= 1 && MB <= 2 && NKX >= 1 && (NTAPS == 1 || NTAPS == 3), "tile geometry");
-  constexpr bool Q2L = kQ2Late && DEFER && !DEEP && (NG + NT - 1) / NT == 1 && NT >= NG + MT;   // free slots behind the DMA pieces
+  constexpr bool Q2L = !M16 && kQ2Late && DEFER && !DEEP && (NG + NT - 1) / NT == 1 && NT >= NG + MT;   // free slots behind the DMA pieces
+  // M16: GEMM 1 on 16x16x32 MFMAs (same tile, same loads, same FLOPs per K-step; the matrix pipe holds a higher clock on
+  // them -- DESIGN.md section 3).  A K-step is two 32-deep sub-steps s; quarter g = (s = g >> 1, column half g & 1) runs
+  // the wave's four 16-row tiles m (tanh rows 0-15, 16-31, sigmoid rows 0-15, 16-31 of its channel block) against the
+  // half's NT 16-column tiles.  Accumulator acc[mt][c][4 v + r], v = 2 (m & 1) + (column tile & 1): lane (j = lane & 15,
+  // g4 = lane >> 4) holds channel 16 (m & 1) + 4 g4 + r of column 32 c + 16 (tile & 1) + j.
+  static_assert(!M16 || (MODE == 0 && MB == 1 && DEFER && !DEEP && NT >= 2), "16x16x32 variant");
   static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && ((NKX >= 4 && NKX % 2 == 0) || NKX == 3)), "deep prefetch variant");
   static_assert(MODE == 0 || (TPW == 1 && CX == ((MODE == 2 || MODE == 4) ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
@@ -237,6 +243,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   unsigned pvoff[NG];     // x planes: byte offset of this lane's piece inside a tile of BN contiguous rows
   int pchunk[NG];         // logical 16-byte chunk (0..7) this lane fetches
   int swB;
+  int l15 = lane & 15, l4 = lane >> 4;   // M16: column / K group of the 16x16x32 operands
   unsigned a_voff;
   auto set_lane_ids = [&]() {
     int t = tid;
@@ -244,7 +251,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     lane = t & 63;
     ln = lane & 31;
     lh = lane >> 5;
-    swB = (ln >> 1) & 7;
+    swB = M16 ? (lane >> 1) & 7 : (ln >> 1) & 7;
+    l15 = lane & 15;
+    l4 = lane >> 4;
     a_voff = lane * 16;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
@@ -299,6 +308,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int c = (k16 * 2 + lh) ^ swB;
     return *(const half8*)(buf + n * 128 + c * 16);
   };
+  // M16: fragment of quarter g, tile nt: columns 16 (NT (g & 1) + nt) + j, K = 32 (g >> 1) + 8 g4 .. + 7
+  auto read_B16 = [&](const char* buf, int g, int nt) -> half8 {
+    const int n = (NT * (g & 1) + nt) * 16 + l15;
+    const int c = (4 * (g >> 1) + l4) ^ swB;
+    return *(const half8*)(buf + n * 128 + c * 16);
+  };
   // A fragments, packed [half K-step][wave][MT][2 k16][64 lanes][8]: tap steps from wA1, conditioning steps from
   // this tile's phase block of wA1c.  q[g][mt] holds the fragment of k16 sub-step g (0..3) of the current K-step;
   // one fragment = one 1 KiB wave-load straight from L2.
@@ -312,6 +327,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #else
     asm volatile("" : "=v"(dst));
 #endif
+  };
+  // M16: [half K-step = sub-step s][wave][tile m][64 lanes = (row i, K group)][8]; fragment (s, m) lives in q[2 s + (m >> 1)][m & 1]
+  auto load_A16 = [&](int ks, int s_, int m, half8& dst) {
+    const char* base = ks < NKX ? (const char*)a.wA1 : wA1c_p;
+    const int kl = ks < NKX ? ks : ks - NKX;
+    gload16<0>(dst, base + ((size_t)(2 * kl + s_) * NW + wave) * (NAH * 1024) + m * 1024, a_voff);
   };
   // column -> (utterance, frame): rr = row inside the phase block, one of the BN consecutive rows of the current tile.
   // The utterance of the tile's first row (tile_b0, wave-uniform: one scalar division per tile) is at most one
@@ -404,9 +425,12 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         for (int mt = 0; mt < MT; ++mt) load_Aq(1, g, mt, Q[DEEP ? 1 : 0][g][mt]);
     } else {
 #pragma unroll
-      for (int g = 0; g < (Q2L ? 2 : 3); ++g)
+      for (int g = 0; g < (Q2L || M16 ? 2 : 3); ++g)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) load_Aq(0, g, mt, q[g][mt]);
+        for (int mt = 0; mt < MT; ++mt) {
+          if constexpr (M16) load_A16(0, 0, 2 * g + mt, q[g][mt]);
+          else load_Aq(0, g, mt, q[g][mt]);
+        }
     }
     // mel rows of the frames this lane gathers for the conditioning K-steps
     if constexpr (MODE == 0) {
@@ -430,6 +454,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     WG_STAMP(0);
     // ---- GEMM1 accumulators start from the bias
     f32x16 acc[MT][NT];
+    f32x4 acc4[M16 ? MT : 1][M16 ? NT : 1][4];     // M16: the same accumulators as four independent 4-register tuples
+    auto acc_at = [&](int mt, int nt, int e) -> float {
+      if constexpr (M16) return acc4[mt][nt][e >> 2][e & 3];
+      else return acc[mt][nt][e];
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       f32x16 v;
@@ -438,15 +467,22 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         for (int j = 0; j < 16; ++j) v[j] = 0.0f;
       } else {
         const int row0 = (mt < MB ? 0 : C) + (wave * MB + (mt < MB ? mt : mt - MB)) * 32;
-        const float4* bp = (const float4*)(sBias + row0 + 4 * lh);
+        const float4* bp = (const float4*)(sBias + row0 + 4 * (M16 ? l4 : lh));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 q4 = bp[2 * g];
+          const float4 q4 = bp[M16 ? 4 * (g >> 1) : 2 * g];
           v[4 * g] = q4.x; v[4 * g + 1] = q4.y; v[4 * g + 2] = q4.z; v[4 * g + 3] = q4.w;
         }
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v;
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (M16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc4[mt][nt][e] = f32x4{v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]};
+        } else {
+          acc[mt][nt] = v;
+        }
+      }
     }
 
     constexpr bool PIPE = !PLAIN && kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
@@ -485,9 +521,18 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lpa%=\n\ts_setprio 0\n\ts_branch .Lpb%=\n.Lpa%=:\n\ts_setprio 1\n.Lpb%=:" :: "s"(wave) : "memory", "scc");
     };
     auto mfma_col = [&](int g, int nt) {
+      if constexpr (M16) {
+        const int t16 = NT * (g & 1) + nt;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[g][mt], bf[g & 1][nt], acc[mt][nt], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) {
+          f32x4& t = acc4[m >> 1][t16 >> 1][2 * (m & 1) + (t16 & 1)];
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(q[2 * (g >> 1) + (m >> 1)][m & 1], bf[g & 1][nt], t, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[g][mt], bf[g & 1][nt], acc[mt][nt], 0, 0, 0);
+      }
     };
     // more: step ks+1 exists; ncond: step ks+1 is a conditioning step; first: no deferred MFMAs pending
     auto kstep = [&](auto more_tag, auto ncond_tag, auto first_tag, int ks) {
@@ -500,7 +545,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       if constexpr (more && ncond && MODE != 0) src_next = sp_src(p, jt, ks + 1 - NKX);
       const unsigned lds_next = sB_addr + ((ks + 1 + par) & 1) * BT_BYTES + wave * 1024;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = read_B(buf, nt, 0);
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = M16 ? read_B16(buf, 0, nt) : read_B(buf, nt, 0);
       __builtin_amdgcn_sched_barrier(0);
       auto dma_slot = [&](int nt) {
         if constexpr (more) {
@@ -533,16 +578,30 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       }
 #pragma unroll
       for (int g = 0; g < (DEFER ? 3 : 4); ++g) {
+        if constexpr (M16) {
+          // VMEM issue order per step: DMA x NG (D slots), A(ks, sub-step 1) x 4 (quarter 0 slots), A(ks+1, sub-step 0) x 4
+          // (quarter 2 slots).  Sub-step 0's fragments are used by quarters 0 and 1, sub-step 1's by quarter 2 and D.
+          if (g == 0) wait_vm<more ? NG : 0>();                  // A(ks, sub-step 0) landed
+          if (g == 2) wait_vm<0>();                              // A(ks, sub-step 1) landed (and the B tile of step ks+1)
+        } else {
         if (g == 1) wait_vm<more ? 2 * MT + NG : 2 * MT>();      // q[1] landed
         if (g == 2) wait_vm<Q2L ? (more ? 2 * MT : MT) : (more ? NG + 2 * MT : MT)>();          // q[2] landed
         if (g == 3) wait_vm<more ? 2 * MT : 0>();                // q[3] landed (no deferral)
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           mfma_col(g, nt);
           __builtin_amdgcn_sched_barrier(0);
-          if (g < 3) bf[(g + 1) & 1][nt] = read_B(buf, nt, g + 1);
+          if (g < 3) bf[(g + 1) & 1][nt] = M16 ? read_B16(buf, g + 1, nt) : read_B(buf, nt, g + 1);
           if (!DEFER && g == 0) dma_slot(nt);
-          if (g == 0 || more) {
+          if constexpr (M16) {
+            constexpr int LP16 = (4 + NT - 1) / NT;
+            if (g == 0 || (g == 2 && more)) {
+#pragma unroll
+              for (int m = nt * LP16; m < (nt + 1) * LP16 && m < 4; ++m)
+                load_A16(g == 0 ? ks : ks + 1, g == 0 ? 1 : 0, m, q[(g == 0 ? 2 : 0) + (m >> 1)][m & 1]);
+            }
+          } else if (g == 0 || more) {
 #pragma unroll
             for (int mt = nt * LPS; mt < (nt + 1) * LPS && mt < MT; ++mt)
               load_Aq(g == 0 ? ks : ks + 1, (g + 3) & 3, mt, q[(g + 3) & 3][mt]);
@@ -554,11 +613,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         }
       }
       if constexpr (more) {
-        if constexpr (DEFER && !Q2L) {
+        if constexpr (DEFER && !Q2L && !M16) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) load_Aq(ks + 1, 2, mt, q[2][mt]);
         }
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(Q2L ? MT : 2 * MT) : "memory");   // DMA, q[0] landed; reads done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(M16 ? 4 : Q2L ? MT : 2 * MT) : "memory");   // DMA, q[0] landed; reads done
 #ifndef WG_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
@@ -851,6 +910,16 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     // hi+lo fp16 (rows 0-7 / 8-15 of the 16x16x32 MFMA) so the 8 flow outputs keep ~fp32 weights.  Two parts: the
     // loads (weight fragments, the out rows to update) are issued early, the MFMAs run once every acts row is in LDS.
     const int l15 = laneo & 15, l4 = laneo >> 4;
+    // M16: the gate's lane holds 4 consecutive channels (16 mh + 4 g4 + r) of its column per 16-row tile: positions
+    // 16 (g4 & 1) + 8 mh + 4 (g4 >> 1) + r of the position-major acts row (wg_common.h chan_to_pos), 8 bytes per write
+    char* const acts_lane16 = sActs + l15 * ACT_ROW + (l4 & 1) * 32 + (l4 >> 1) * 8;
+    auto write_acts16 = [&](int c, int blk_, int mh, const half8& o) {
+      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+      const half4_t lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
+      char* ap = acts_lane16 + c * 32 * ACT_ROW + blk_ * 64 + mh * 16;
+      *(half4_t*)(ap) = lo;                       // column tile 2 c
+      *(half4_t*)(ap + 16 * ACT_ROW) = hi;        // column tile 2 c + 1
+    };
     constexpr int NGRP = (BN / 16 + NW - 1) / NW;            // 16-column groups per wave
     constexpr bool kWesEarly = (C / 32) * 4 <= 32;           // folded-end weight fragments fit beside GEMM2's registers
     half8 wes[C / 32];
@@ -991,9 +1060,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         half8 o0, o1, th0, th1, sg0, sg1;                     // th / sg: training forward only (saved tanh, sigmoid)
         auto stageA = [&](int e) {
           const int nt = c < NT ? c : 0;
-          const float u = __builtin_amdgcn_fmed3f(acc[0][nt][e], -60.0f, 60.0f);
+          const float u = __builtin_amdgcn_fmed3f(acc_at(0, nt, e), -60.0f, 60.0f);
           e1[e] = __builtin_amdgcn_exp2f(u);
-          den[e] = __builtin_amdgcn_exp2f(TR ? __builtin_amdgcn_fmed3f(acc[MB][nt][e], -60.0f, 60.0f) : acc[MB][nt][e]);
+          den[e] = __builtin_amdgcn_exp2f(TR ? __builtin_amdgcn_fmed3f(acc_at(MB, nt, e), -60.0f, 60.0f) : acc_at(MB, nt, e));
         };
         auto stageB = [&](int e) {
           const float t = 1.0f + den[e];
@@ -1043,8 +1112,13 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             if (i + 2 < SL) stageA(i + 2);
             if (i + 1 < SL) stageB(i + 1);
             if (i & 1) { stageC(i - 1); stageC(i); }
-            if (i == 7) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64) = o0;          // positions [32 blk + 16 h, +8)
-            if (i == SL - 1) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64 + 16) = o1;
+            if constexpr (M16) {
+              if (i == 7) write_acts16(c, blk, 0, o0);
+              if (i == SL - 1) write_acts16(c, blk, 1, o1);
+            } else {
+              if (i == 7) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64) = o0;          // positions [32 blk + 16 h, +8)
+              if (i == SL - 1) *(half8*)(acts_lane + c * 32 * ACT_ROW + blk * 64 + 16) = o1;
+            }
             if constexpr (TR) {
               // saved activations: rows of padding columns stay zero (cleared once per workspace geometry), the
               // weight-gradient kernels sum over every row of a phase
@@ -1137,13 +1211,18 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         } else {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            o0[r] = (_Float16)gate_act(acc[mb][nt][r], acc[MB + mb][nt][r]);
-            o1[r] = (_Float16)gate_act(acc[mb][nt][8 + r], acc[MB + mb][nt][8 + r]);
+            o0[r] = (_Float16)gate_act(acc_at(mb, nt, r), acc_at(MB + mb, nt, r));
+            o1[r] = (_Float16)gate_act(acc_at(mb, nt, 8 + r), acc_at(MB + mb, nt, 8 + r));
           }
         }
-        char* ap = acts_lane + nt * 32 * ACT_ROW + (wave * MB + mb) * 64;   // positions [32*blk + 16h, +16)
-        *(half8*)(ap) = o0;
-        *(half8*)(ap + 16) = o1;
+        if constexpr (M16) {
+          write_acts16(nt, wave * MB + mb, 0, o0);
+          write_acts16(nt, wave * MB + mb, 1, o1);
+        } else {
+          char* ap = acts_lane + nt * 32 * ACT_ROW + (wave * MB + mb) * 64;   // positions [32*blk + 16h, +16)
+          *(half8*)(ap) = o0;
+          *(half8*)(ap + 16) = o1;
+        }
       }
     }
     __syncthreads();
@@ -1234,6 +1313,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 template <int C, int BN, bool HAS_RES, int TPW, int CX, int MODE = 0, int NTAPS = 3, bool HAS_COND = true, bool DEEP = false>
 static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
+  constexpr bool M16 = wn_frag16(C, BN) && MODE == 0 && !DEEP;   // the host packs GEMM-1 weights for it (api.cpp)
+  if (M16 != (a.frag16 != 0)) return hipErrorInvalidValue;
   constexpr int smem = MODE == 4 ? (BN * (2 * C + 16) > 2 * BN * 128 ? BN * (2 * C + 16) : 2 * BN * 128)
                                  : 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
@@ -1241,7 +1322,7 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
   bool& attr_done = attr_done_dev[cur_dev];
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP>,
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP, M16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
@@ -1249,7 +1330,7 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   // TPW tiles per workgroup: per XCD label ceil(tiles_on_label / TPW) blocks
   const int per_label = ((a.n_tiles + 7) / 8 + TPW - 1) / TPW;
   const int grid = 8 * per_label;
-  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP>), dim3(grid), dim3(NW * 64), smem, s, a);
+  hipLaunchKernelGGL((wn_layer_kernel<C, NW, BN, HAS_RES, TPW, CX, MODE, NTAPS, HAS_COND, DEEP, M16>), dim3(grid), dim3(NW * 64), smem, s, a);
   return hipGetLastError();
 }
 template <int C, int BN, bool HAS_RES, int TPW>
@@ -1422,7 +1503,7 @@ hipError_t launch_mel_pack(const MelPackArgs& a, hipStream_t s) {
 // [l][p][half K-step][wave][MT][2 k16][64 lanes][8]   (K index kk = j*M + i; see wn_layer_kernel::load_Aq).
 __global__ void __launch_bounds__(256) cond_fold_kernel(const float* __restrict__ w_cond, const float* __restrict__ w_up,
                                                         _Float16* __restrict__ out, int C, int NW, int M, int up_kernel,
-                                                        float tanh_scale, float sigm_scale) {
+                                                        float tanh_scale, float sigm_scale, int frag16) {
   __shared__ float sW[64][33];    // W_cond rows m0..m0+63, s-chunk of 32
   __shared__ float sU[32][81];    // U[s][i] = W_up[i][o][8p+g+256j]
   const int p = blockIdx.x >> 2, j = blockIdx.x & 3;
@@ -1469,17 +1550,24 @@ __global__ void __launch_bounds__(256) cond_fold_kernel(const float* __restrict_
     const int w = blk / MB, mt = (tanh_row ? 0 : MB) + (blk - w * MB);
     const int kk = j * M + i;
     const int u = kk >> 5, k2 = (kk >> 4) & 1, hh = (kk >> 3) & 1, jj = kk & 7;
+    const _Float16 val = (_Float16)(acc[e] * (tanh_row ? tanh_scale : sigm_scale));
+    if (frag16) {        // 16x16x32 A fragments (wn_layer_kernel M16): [..][half K-step][wave][tile m][(row i, K group)][8]
+      const int m16 = 2 * (tanh_row ? 0 : 1) + (r >> 4), kg = (kk >> 3) & 3;
+      const size_t f16 = (((size_t)(l * kPhases + p) * n_half + u) * NW + w) * 4 + m16;
+      out[(f16 * 64 + kg * 16 + (r & 15)) * 8 + jj] = val;
+      continue;
+    }
     const size_t frag = ((((size_t)(l * kPhases + p) * n_half + u) * NW + w) * MT + mt) * 2 + k2;
-    out[(frag * 64 + hh * 32 + r) * 8 + jj] = (_Float16)(acc[e] * (tanh_row ? tanh_scale : sigm_scale));
+    out[(frag * 64 + hh * 32 + r) * 8 + jj] = val;
   }
 }
 
 hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* out, int C, int NW, int M, int n_layers,
-                            int up_kernel, float tanh_scale, float sigm_scale, hipStream_t s) {
-  if (M > 80 || M % 16) return hipErrorInvalidValue;
+                            int up_kernel, float tanh_scale, float sigm_scale, int frag16, hipStream_t s) {
+  if (M > 80 || M % 16 || (frag16 && C != 32 * NW)) return hipErrorInvalidValue;
   dim3 grid(kPhases * 4, 2 * C / 64, n_layers);
   hipLaunchKernelGGL(cond_fold_kernel, grid, dim3(256), 0, s, w_cond, w_up, out, C, NW, M, up_kernel, tanh_scale,
-                     sigm_scale);
+                     sigm_scale, frag16);
   return hipGetLastError();
 }
 

@@ -60,6 +60,14 @@ constexpr int kRowPad = 16;      // zero slack rows in front of / behind every p
 #endif
 constexpr int kPhases = 32;
 
+// GEMM 1 of the inference layer on 16x16x32 MFMAs (wn_layer_kernel M16) for this tile shape: its A fragments are packed
+// differently (api.cpp wg_finalize packs both orders when a model can run either tile width)
+#ifdef WG_NO_M16                 // A/B builds only
+constexpr bool wn_frag16(int, int) { return false; }
+#else
+constexpr bool wn_frag16(int C, int BN) { return C == 256 && BN == 128; }
+#endif
+
 struct WnLayerArgs {
   const _Float16* x_in;     // [C/64][R][64] position-major
   const _Float16* x_tap;    // B operand of the three dilated taps of GEMM 1: x_in, or for the first layer of a WN the
@@ -85,6 +93,7 @@ struct WnLayerArgs {
   int tiles_per_phase;      // tiles of this launch per phase: (Rp - row0) / BN, or fewer
   int n_tiles;              // 32 * tiles_per_phase
   int n_cu;                 // compute units of the device (persistent grid size)
+  int frag16 = 0;           // wA1 / wA1c are 16x16x32 fragments (must equal wn_frag16(C, BN) of the inference launch)
   unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
   // ---- training forward only (wn_layer_kernel<..., TR = true>, train_api.cpp); null / unused for inference
   const _Float16* sp;       // upsampled, squeezed spectrogram planes [M8/64 chunks][R][64] (position-major): the B operand
@@ -154,7 +163,7 @@ hipError_t launch_mel_pack(const MelPackArgs& a, hipStream_t s);
 hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t s);   // 16-byte aligned pointer and size
 // derived weights: A fragments of (W_cond slice of layer l) x (upsample taps of phase p), see api.cpp
 hipError_t launch_cond_fold(const float* w_cond, const float* w_up, _Float16* out, int C, int NW, int M, int n_layers,
-                            int up_kernel, float tanh_scale, float sigm_scale, hipStream_t s);
+                            int up_kernel, float tanh_scale, float sigm_scale, int frag16, hipStream_t s);
 hipError_t launch_flow(const FlowArgs& a, hipStream_t s);
 hipError_t launch_wn_layer(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // bn = 128 (default) or 64
 hipError_t launch_wn_layer_train(const WnLayerArgs& a, int C, int bn, hipStream_t s);   // training forward (a.sp, a.save_*)
