@@ -157,6 +157,12 @@ constexpr bool kDeep = false;         // A/B builds: the one-step ring for small
 constexpr bool kDeep = true;
 #endif
 
+// 16x16x32 MFMA of the M16 K loop.  (Measured: the same instruction as an asm statement accumulating in place -- hipcc
+// cannot then give a result a fresh destination tuple -- -0.16 % same-box, and hipcc no longer sees the MFMA hazards.)
+__device__ __forceinline__ void mfma16_acc(f32x4& c, const half8& a, const half8& b) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 template <int C> struct WnCfg {
   static constexpr int NW = (C >= 256) ? 8 : C / 32;   // waves per workgroup
   static constexpr int BN = (C >= 512) ? 64 : 128;     // columns (group-timesteps) per workgroup
@@ -525,13 +531,22 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         const int t16 = NT * (g & 1) + nt;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          f32x4& t = acc4[m >> 1][t16 >> 1][2 * (m & 1) + (t16 & 1)];
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(q[2 * (g >> 1) + (m >> 1)][m & 1], bf[g & 1][nt], t, 0, 0, 0);
+          mfma16_acc(acc4[m >> 1][t16 >> 1][2 * (m & 1) + (t16 & 1)], q[2 * (g >> 1) + (m >> 1)][m & 1], bf[g & 1][nt]);
         }
       } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+#ifdef WG_DBG_MFMA16   // timing experiment only (results are garbage): the 32x32x16 loop's loads and schedule, two 16x16x32 MFMAs each
+          f32x4 lo = __builtin_shufflevector(acc[mt][nt], acc[mt][nt], 0, 1, 2, 3);
+          f32x4 hi = __builtin_shufflevector(acc[mt][nt], acc[mt][nt], 4, 5, 6, 7);
+          lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(q[g][mt], bf[g & 1][nt], lo, 0, 0, 0);
+          hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(q[g][mt], bf[g & 1][nt], hi, 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[mt][nt][j] = lo[j]; acc[mt][nt][4 + j] = hi[j]; }
+#else
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[g][mt], bf[g & 1][nt], acc[mt][nt], 0, 0, 0);
+#endif
+        }
       }
     };
     // more: step ks+1 exists; ncond: step ks+1 is a conditioning step; first: no deferred MFMAs pending
@@ -581,6 +596,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
         if constexpr (M16) {
           // VMEM issue order per step: DMA x NG (D slots), A(ks, sub-step 1) x 4 (quarter 0 slots), A(ks+1, sub-step 0) x 4
           // (quarter 2 slots).  Sub-step 0's fragments are used by quarters 0 and 1, sub-step 1's by quarter 2 and D.
+          // (Measured and dropped: quarter 1 and D fragment-major -- slot m = tile m against all columns -- so that fragment
+          // m is dead after slot m and its successor goes out two quarters before its first use: -0.6 % same-box.)
           if (g == 0) wait_vm<more ? NG : 0>();                  // A(ks, sub-step 0) landed
           if (g == 2) wait_vm<0>();                              // A(ks, sub-step 1) landed (and the B tile of step ks+1)
         } else {
