@@ -93,6 +93,7 @@ struct LayerOffsets {
 struct FlowOffsets {
   std::vector<LayerOffsets> layers;
   size_t wstart, bstart, out_init, winv, wfwd;
+  size_t wStA = 0;   // start weights as the A fragment of the first layer's residual step (wn_res_a0)
   int c, h;
   double logdet;   // log|det W_k|, NaN when det < 0 (torch.logdet semantics, model.py:63)
 };
@@ -488,6 +489,22 @@ int wg_finalize(wg_handle* h) {
         bs[P] = bst->data[ch];
       }
     }
+    if (wn_res_a0(C)) {
+      // A fragment of the 32x32x16 MFMA, [wave][lane = (row r, half)][8]: row r = channel 32 w + r; lanes 0-31 hold the fp16
+      // hi parts of (W_start[ch][0..h-1], b_start[ch] at k = 4), lanes 32-63 the lo parts -- against the a0 plane row, which
+      // carries (a0 | 1 | 0 0 0) at positions 0-7 and again at 8-15 (flow_kernel)
+      fo.wStA = reserve((size_t)NW * 64 * 8 * 2);
+      _Float16* d = (_Float16*)(blob.data() + fo.wStA);
+      for (int w = 0; w < NW; ++w)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int ch = 32 * w + (lane & 31);
+          for (int j = 0; j < 8; ++j) {
+            const float v = j < hk ? wst->data[(size_t)ch * hk + j] : j == 4 ? bst->data[ch] : 0.0f;
+            const _Float16 hi = (_Float16)v;
+            d[((size_t)w * 64 + lane) * 8 + j] = lane < 32 ? hi : (_Float16)(v - (float)hi);
+          }
+        }
+    }
     std::vector<double> out_bias(8, 0.0);
     for (int r = 0; r < 2 * hk; ++r) out_bias[r] = bend->data[r];
     fo.layers.assign(NL, LayerOffsets());
@@ -737,6 +754,7 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.x_chunks_per_tap = fold0 ? 1 : C / 64;
     a.melT = w.melT;
     a.frag16 = wn_frag16(C, BN) ? 1 : 0;
+    a.wStA = fold0 && wn_res_a0(C) ? (const _Float16*)(h->d_blob + fo.wStA) : nullptr;
     a.wA1c = (const _Float16*)((a.frag16 ? h->d_cond16 : h->d_cond) + h->cond_flow_bytes * k + h->cond_layer_bytes * i);
     a.wA1 = (const _Float16*)(h->d_blob + (a.frag16 ? (fold0 ? lo.wA1fx : lo.wA1x) : (fold0 ? lo.wA1f : lo.wA1)));
     a.bias1 = (const float*)(h->d_blob + lo.bias1);
@@ -842,6 +860,7 @@ int wg_infer_ragged(wg_handle* h, const void* mel, const int32_t* frames, const 
     f.out_init = (const float*)(h->d_blob + h->flows[k].out_init);
     f.x = cur;
     f.a0p = w.A0;
+    f.skip_x = h->fold_start && wn_res_a0(C);
     Prof p(h, s, 1);
     HIP_TRY(launch_flow(f, s));
   }
@@ -871,6 +890,7 @@ int wg_infer_ragged(wg_handle* h, const void* mel, const int32_t* frames, const 
       f.out_init = (const float*)(h->d_blob + h->flows[k - 1].out_init);
       f.x = cur;
       f.a0p = w.A0;
+      f.skip_x = h->fold_start && wn_res_a0(C);
     }
     Prof p(h, s, 1);
     HIP_TRY(launch_flow(f, s));
@@ -952,6 +972,7 @@ int wg_forward(wg_handle* h, const void* mel, const void* audio, float* z, float
       f.out_init = (const float*)(h->d_blob + h->flows[k].out_init);
       f.x = cur;
       f.a0p = w.A0;
+      f.skip_x = h->fold_start && wn_res_a0(C);
       z_ch += f.n_peel;
     }
     {

@@ -492,6 +492,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     }
 
     constexpr bool PIPE = !PLAIN && kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
+    constexpr bool RES_A0 = MODE == 0 && CX == 1 && wn_res_a0(C);       // first layer of a WN: x_0 rebuilt from the a0 plane
+    static_assert(!RES_A0 || (PIPE || !HAS_RES), "the a0 residual step lives in the pipelined epilogue");
     half8 a2r[PIPE ? K2 : 1];                                 // GEMM-2 weight fragments of this wave (pipelined epilogue)
     // ---- K loop (GEMM 1).  One K-step = 4 k16 sub-steps g = 0..3, each MT*NT MFMAs on fragments q[g][.]
     // (weights) x bf[g&1][.] (activations, read from LDS one sub-step ahead).  Every VMEM / LDS instruction is
@@ -1022,20 +1024,29 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       // channel r of the block, k = storage position chan_to_pos(r)) and whose B fragments are the x rows themselves,
       // loaded straight in B-fragment order.  x (fp16) times 1.0 accumulated in fp32 is exact, and it replaces 32 VALU
       // instructions per chunk (16 cvt + 16 add) in phases that are VALU-bound while the matrix pipe has room.
-      half8 idA[2];
-      {
+      // First layer of a WN (RES_A0): x_0 = W_start a0 + b_start was never stored -- ONE k16 step against the a0 plane row
+      // (a0 | 1 | 0 0 0, twice) with the start weights as A fragment: lanes 0-31 the fp16 hi parts (k = 0..4), lanes 32-63 the
+      // lo parts (k = 8..12), so the sum carries ~fp32 weights and is never rounded to fp16 on its own.
+      half8 idA[RES_A0 ? 1 : 2];
+      if constexpr (RES_A0) {
+        idA[0] = ((const half8*)a.wStA)[wave * 64 + laneo];
+      } else {
         const int pr = 16 * ((lno >> 2) & 1) + 4 * (lno >> 3) + (lno & 3);     // chan_to_pos of row r = lno inside a 32-block
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
           for (int j = 0; j < 8; ++j) idA[sx][j] = (_Float16)((16 * sx + 8 * lho + j) == pr ? 1.0f : 0.0f);
       }
-      half8 xr[2];                                            // residual x of the chunk whose GEMM 2 runs next (B fragments)
+      half8 xr[RES_A0 ? 1 : 2];                               // residual x of the chunk whose GEMM 2 runs next (B fragments)
       auto load_xr = [&](int nt) {
-        const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
-        const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lho * 8);
-        xr[0] = xp[0];                                        // positions 8h .. 8h+7       (k16 step 0)
-        xr[1] = xp[2];                                        // positions 16 + 8h .. +7    (k16 step 1)
+        if constexpr (RES_A0) {
+          xr[0] = *(const half8*)(a.x_tap + ((size_t)r0 + nt * 32 + lno) * 64 + lho * 8);
+        } else {
+          const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
+          const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lho * 8);
+          xr[0] = xp[0];                                        // positions 8h .. 8h+7       (k16 step 0)
+          xr[1] = xp[2];                                        // positions 16 + 8h .. +7    (k16 step 1)
+        }
       };
       load_xr(0);
       // (Measured and dropped: storing a chunk's x_out rows one phase late, inside the next phase's slots, to keep the wait
@@ -1067,7 +1078,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
             d2[4 * g + 3] = b4.w;
           }
           d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[0], xr[0], d2, 0, 0, 0);
-          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[1], xr[1], d2, 0, 0, 0);
+          if constexpr (!RES_A0) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA[1], xr[1], d2, 0, 0, 0);
         }
         if (do_mm && c < NT) load_xr(c);                      // residual of chunk c: phase c+1 starts from it
         if (c == NT - 1) es_prefetch();                       // end x skip out rows (and weights, without kWesLds): consumed in the last phase
@@ -1332,6 +1343,7 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr bool M16 = wn_frag16(C, BN) && MODE == 0 && !DEEP;   // the host packs GEMM-1 weights for it (api.cpp)
   if (M16 != (a.frag16 != 0)) return hipErrorInvalidValue;
+  if (MODE == 0 && CX == 1 && wn_res_a0(C) && HAS_RES && !a.wStA) return hipErrorInvalidValue;
   constexpr int smem = MODE == 4 ? (BN * (2 * C + 16) > 2 * BN * 128 ? BN * (2 * C + 16) : 2 * BN * 128)
                                  : 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
@@ -1744,11 +1756,12 @@ __global__ void __launch_bounds__(FL_ROWS) flow_kernel(const FlowArgs a) {
           o[4] = (_Float16)1.0f;
           const size_t prow = (size_t)kRowPad + (size_t)(t & 31) * a.g.Rp + (size_t)b * a.g.Fp + a.g.Gf + (t >> 5);
           *(half8*)(a.a0p + prow * 64) = o;
+          *(half8*)(a.a0p + prow * 64 + 8) = o;     // again at 8..12: the lo weight parts of the first layer's residual step
         }
       }
     }
   }
-  if (a.last) return;
+  if (a.last || a.skip_x) return;
   __syncthreads();
 
   // ---- WN.start of the next flow (model.py:117): x[P] = sum_j Wst[P][j] a0[j] + b[P], fp16, position-major.

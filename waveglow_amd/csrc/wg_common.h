@@ -68,6 +68,11 @@ constexpr bool wn_frag16(int, int) { return false; }
 constexpr bool wn_frag16(int C, int BN) { return C == 256 && BN == 128; }
 #endif
 
+// First layer of a WN in the inference kernels: the residual input x_0 = W_start a0 + b_start (model.py:117) is rebuilt from
+// the a0 plane by one MFMA step of the epilogue (weights hi + lo fp16, WnLayerArgs::wStA), so flow_kernel does not write
+// the x_0 planes at all (2C bytes per group-timestep and flow).  Channel counts whose kernels have the pipelined epilogue.
+constexpr bool wn_res_a0(int C) { return C == 128 || C == 256; }
+
 struct WnLayerArgs {
   const _Float16* x_in;     // [C/64][R][64] position-major
   const _Float16* x_tap;    // B operand of the three dilated taps of GEMM 1: x_in, or for the first layer of a WN the
@@ -94,6 +99,8 @@ struct WnLayerArgs {
   int n_tiles;              // 32 * tiles_per_phase
   int n_cu;                 // compute units of the device (persistent grid size)
   int frag16 = 0;           // wA1 / wA1c are 16x16x32 fragments (must equal wn_frag16(C, BN) of the inference launch)
+  const _Float16* wStA = nullptr;   // first layer with the start fold (x_chunks_per_tap == 1), wn_res_a0(C): [NW][64][8] A fragments
+                            // (row r = channel 32 w + r; k = 0..3 W_start, k = 4 b_start; lanes 0-31 hi, 32-63 lo parts)
   unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
   // ---- training forward only (wn_layer_kernel<..., TR = true>, train_api.cpp); null / unused for inference
   const _Float16* sp;       // upsampled, squeezed spectrogram planes [M8/64 chunks][R][64] (position-major): the B operand
@@ -151,7 +158,8 @@ struct FlowArgs {
   float* Z_w;               // where the new state / re-initialised out are written: = Z / out for inference (in place);
   float* out_w;             // the training forward keeps every flow's state and gives each flow its own buffers
   _Float16* x;              // [C/64][R][64] start output
-  _Float16* a0p;            // [1][R][64] a0 plane: channels 0..3 = a0 (fp16), channel 4 = 1, rest 0 (or null)
+  _Float16* a0p;            // [1][R][64] a0 plane: channels 0..3 = a0 (fp16), channel 4 = 1, 8..12 the same again, rest 0 (or null)
+  int skip_x;               // do not write the x planes (the next WN's first layer rebuilds x_0 from the a0 plane, wn_res_a0)
   void* audio_out;          // infer+last: [B][8L] io dtype
   RowGeom g;
   int C;
