@@ -129,6 +129,11 @@ constexpr bool kPrio = true;
 // q[2] of a K-step is fetched in the load-free slots of the step's own deferred sub-step (behind the DMA pieces) instead of
 // as two loads back to back at the end of the step before, where nothing covers their issue; the step then ends with the
 // counted wait and the barrier alone.  Same-box A/B +0.25 % (0.6143 -> 0.6158), training neutral.
+#ifdef WG_NO_TILE_INTERLEAVE
+constexpr bool kTileInterleave = false;   // A/B builds
+#else
+constexpr bool kTileInterleave = true;
+#endif
 #ifdef WG_NO_Q2_LATE
 constexpr bool kQ2Late = false;       // A/B builds
 #else
@@ -370,6 +375,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   // kTilesPerWG tiles.  (A real persistent loop makes hipcc spill 100+ VGPRs around the back edge.)
   int tile, tile_end;
   const int tile_step = gridDim.x >> 3;        // grid is a multiple of 8
+  int run_start, run_quarter = 0;              // this XCD's run of tiles; a quarter of it (0: run not divisible by 4)
   {
     const int bid = blockIdx.x, ntl = a.n_tiles;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -377,16 +383,23 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     const int start = xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq;
     tile_end = start + (xcd < r ? qq + 1 : qq);
     tile = start + idx;
+    run_start = start;
+    if (kTileInterleave && ((tile_end - start) & 3) == 0) run_quarter = (tile_end - start) >> 2;
   }
+  // Walk order inside the run: index i takes tile (i & 3) * quarter + (i >> 2), so the tiles an XCD works on at one time are
+  // the same few rows of its (typically four) phases instead of 32 consecutive tiles of one phase -- with every XCD doing the
+  // same, a plane row's three uses (centre tap of its own tile, the outer taps of the tiles one dilation away, mostly on other
+  // XCDs) fall close together in time instead of a quarter of the launch apart.
+  auto tile_of = [&](int t) { return run_quarter ? run_start + ((t - run_start) & 3) * run_quarter + ((t - run_start) >> 2) : t; };
 
   // (Measured and dropped: issuing the first tile's step-0 A fragments here, ahead of the bias loads, so that a cold
   // launch pays one memory round trip instead of two -- no gain at batch 1, -0.6 % at config 1.)
   half8 q[4][MT];
   int par = 0;                               // LDS buffer of K-step ks is (ks + par) & 1
   if (tile < tile_end) {
-    const int p0 = tile / a.tiles_per_phase;
+    const int t0 = tile_of(tile), p0 = t0 / a.tiles_per_phase;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) stage_B_piece(p0, tile - p0 * a.tiles_per_phase, 0, 0, i);
+    for (int i = 0; i < NG; ++i) stage_B_piece(p0, t0 - p0 * a.tiles_per_phase, 0, 0, i);
   }
   // bias of GEMM1 (pre-scaled: in_layer bias + cond_layer bias slice + W_cond . upsample bias), fp32 [2C], in LDS
   float* const sBias = (float*)(sActs + BN * ACT_ROW);
@@ -405,8 +418,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   for (int it = 0; it < TPW; ++it, tile += tile_step) {
     if (tile >= tile_end) break;
     if (it > 0) set_lane_ids();
-    const int p = tile / a.tiles_per_phase;           // phase of every column of this tile
-    const int jt = tile - p * a.tiles_per_phase;
+    const int tile_m = tile_of(tile);
+    const int p = tile_m / a.tiles_per_phase;         // phase of every column of this tile
+    const int jt = tile_m - p * a.tiles_per_phase;
     const int rr0 = a.row0 + jt * BN;                 // first row inside the phase block
     tile_b0 = rr0 / Fp;
     const int r0 = kRowPad + p * Rp + rr0;            // first plane row of this tile
@@ -773,9 +787,9 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     // still be reading that one) -- it lands under the phases below.
     if constexpr (kXTileDMA) {
       if (next_tile < tile_end) {
-        const int pn = next_tile / a.tiles_per_phase;
+        const int tn = tile_of(next_tile), pn = tn / a.tiles_per_phase;
 #pragma unroll
-        for (int i = 0; i < NG; ++i) stage_B_piece(pn, next_tile - pn * a.tiles_per_phase, 0, par, i);
+        for (int i = 0; i < NG; ++i) stage_B_piece(pn, tn - pn * a.tiles_per_phase, 0, par, i);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
