@@ -118,6 +118,52 @@ def test_infer_c256_vs_oracle_medium(force_bn, monkeypatch):
     assert err <= RMS_TOL
 
 
+@pytest.mark.parametrize("channels", [128, 256])
+@pytest.mark.parametrize("force_bn", ["128", "64"])
+def test_first_layer_residual_from_a0_plane_matches_x0_planes(channels, force_bn, monkeypatch):
+  """With the start fold the first layer of a WN rebuilds its residual input x_0 = W_start a0 + b_start from the a0
+  plane (one MFMA step, hi + lo fp16 weights) and flow_kernel writes no x_0 planes; WG_NO_START_FOLD=1 (read at model
+  creation) takes the stored fp16 x_0 like every other layer.  Both against the oracle, and against each other much
+  closer than the bar."""
+  from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_FORCE_BN", force_bn)
+  hp = HParams(n_channels=channels, n_layers=4, n_flows=4, n_early_every=2)
+  sd = synthetic.make_state_dict(hp, seed=5)
+  B, T = 2, 37
+  mel = synthetic.make_mel(B, T, seed=3)
+  z_init, z_early = synthetic.make_noise(hp, B, 32 * T, seed=4)
+  with torch.no_grad():
+    ref = O.infer_ref(sd, mel, z_init, z_early, 0.8, oracle_cfg_from_hp(hp))
+  out_fold = gpu_infer(build_model(hp, sd), mel, z_init, z_early, 0.8)
+  monkeypatch.setenv("WG_NO_START_FOLD", "1")
+  out_x0 = gpu_infer(build_model(hp, sd), mel, z_init, z_early, 0.8)
+  monkeypatch.delenv("WG_NO_START_FOLD")
+  assert rms(out_fold - ref) <= RMS_TOL and rms(out_x0 - ref) <= RMS_TOL, (rms(out_fold - ref), rms(out_x0 - ref))
+  assert rms(out_fold - out_x0) <= 0.5 * RMS_TOL, rms(out_fold - out_x0)
+  assert not torch.equal(out_fold, out_x0)          # the two paths are really different code
+
+
+def test_layer_tile_widths_agree_c256(monkeypatch):
+  """256 channels: the 128-column tile runs GEMM 1 on 16x16x32 MFMAs from its own weight packing, the 64-column tile on
+  32x32x16 -- same math from different fragment layouts."""
+  hp = HParams(n_flows=4, n_early_every=2)
+  sd = synthetic.make_state_dict(hp, seed=9)
+  B, T = 3, 50
+  mel = synthetic.make_mel(B, T, seed=1)
+  z_init, z_early = synthetic.make_noise(hp, B, 32 * T, seed=2)
+  outs = {}
+  for bn in ("128", "64"):
+    monkeypatch.setenv("WG_FORCE_BN", bn)
+    outs[bn] = gpu_infer(build_model(hp, sd), mel, z_init, z_early, 0.6)
+  d = rms(outs["128"] - outs["64"])
+  print(f"tile widths: rms diff {d:.3e} (signal {rms(outs['128']):.3f})")
+  assert d <= 0.25 * RMS_TOL, d
+  # ... in fact bit for bit on gfx950: both loops feed every accumulator its K values in the same order (bias, taps,
+  # conditioning; k ascending inside a K-step) and the two MFMA shapes round alike, so a wrong fragment index in either
+  # packing (api.cpp pack16 / cond_fold_kernel frag16) shows up here as a difference, not as a tolerance question
+  assert torch.equal(outs["128"], outs["64"])
+
+
 def test_weights_update_rebuilds_derived_state():
   """The reference caches W_inverse as a plain attribute and goes stale (model.py:52-58); here every packed layout
   incl. W^-1 is re-derived when parameters change -- also after .half()."""
