@@ -596,8 +596,10 @@ int wg_finalize(wg_handle* h) {
                   }
                 }
         if (f16) {
-          lo.wA1fx = reserve((size_t)3 * 2 * NW * 4 * 64 * 8 * 2);
-          pack16(lo.wA1fx, 2 * 3, [&](int m, int tap, int kk) { return kk < 8 ? (float)fold[((size_t)m * 3 + tap) * 8 + kk] : 0.0f; });
+          // ONE K-step for the three taps (wn_layer_kernel A0G): K index kk = 8 tap + j against a B tile whose 16-byte
+          // chunk `tap` is the first chunk (a0 | 1 | 0 0 0) of that tap's a0-plane row
+          lo.wA1fx = reserve((size_t)2 * NW * 4 * 64 * 8 * 2);
+          pack16(lo.wA1fx, 2, [&](int m, int, int kk) { return kk < 24 ? (float)fold[((size_t)m * 3 + (kk >> 3)) * 8 + (kk & 7)] : 0.0f; });
         }
       }
       lo.bias1 = reserve((size_t)2 * C * 4);

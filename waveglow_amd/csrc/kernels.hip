@@ -235,6 +235,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   // half's NT 16-column tiles.  Accumulator acc[mt][c][4 v + r], v = 2 (m & 1) + (column tile & 1): lane (j = lane & 15,
   // g4 = lane >> 4) holds channel 16 (m & 1) + 4 g4 + r of column 32 c + 16 (tile & 1) + j.
   static_assert(!M16 || (MODE == 0 && MB == 1 && DEFER && !DEEP && NT >= 2), "16x16x32 variant");
+  // A0G: first layer of a WN with the start fold, ONE tap K-step instead of three: the a0 plane row carries 5 live values
+  // (a0 | 1), so the three taps' rows fit side by side in one 64-wide B tile -- 16-byte chunk t of tile row n = chunk 0 of
+  // the plane row of tap t (the LDS-DMA takes a per-lane source: stage_B_piece), chunks 3-7 from the rows' own zero tails --
+  // against in_layers[0] o start packed as [tap][8] along K (api.cpp wA1fx).  8 -> 6 K-steps for that launch.
+  constexpr bool A0G = MODE == 0 && CX == 1 && NTAPS == 1;
   static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && ((NKX >= 4 && NKX % 2 == 0) || NKX == 3)), "deep prefetch variant");
   static_assert(MODE == 0 || (TPW == 1 && CX == ((MODE == 2 || MODE == 4) ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
@@ -306,6 +311,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   auto stage_B_piece = [&](int p, int jt, int ks, int bufsel, int i) {
 #ifndef WG_DBG_NO_DMA
     const unsigned lds = __builtin_amdgcn_readfirstlane(sB_addr + bufsel * BT_BYTES + (i * NTHREADS + wave * 64) * 16);
+    if constexpr (A0G) {
+      if (ks < NKX) {
+        const int row = (i * NTHREADS + tid) >> 3, lc = pchunk[i];
+        const int pp = p + ((lc < 3 ? lc : 1) - 1) * a.dil;
+        const unsigned prow = (unsigned)(kRowPad + (pp & 31) * Rp + a.row0 + jt * BN + (pp >> 5) + row);
+        glds16(a.x_tap, prow * 128u + (lc < 3 ? 0u : (unsigned)lc * 16u), lds);
+        return;
+      }
+    }
     if (ks < NKX) glds16(xstep_src(p, jt, ks), pvoff[i], lds);
     else if constexpr (MODE != 0) glds16(sp_src(p, jt, ks - NKX), pvoff[i], lds);
     else glds16(a.melT, cond_voff(ks - NKX, i), lds);
@@ -1387,7 +1401,11 @@ static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
       return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64, 0, 3, true, true>(a, s);
     }
   }
-  if (a.x_chunks_per_tap == 1) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
+  if (a.x_chunks_per_tap == 1) {
+    // first layer with the start fold: the 16x16x32 tile shapes take the three taps in one K-step (A0G; wA1fx is packed for it)
+    if constexpr (wn_frag16(C, BN)) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1, 0, 1>(a, s);
+    return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
+  }
   return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64>(a, s);
 }
 template <int C, int BN, bool HAS_RES>
