@@ -42,17 +42,16 @@ def wn_layer_macs_per_group_step(hp) -> float:
   return total
 
 
-def wn_layer_executed_macs_per_group_step(hp, wide_tiles: bool = False) -> float:
+def wn_layer_executed_macs_per_group_step(hp) -> float:
   """MACs the wn_layer launches actually EXECUTE per group-timestep, after the algebraic folds of DESIGN.md section 2
   (cond_layer o upsample: K 640 -> 320; WN.end folded into the skip rows: the skip half of res_skip and `end` become
-  16 rows; in_layers[0] o start: 3 K-steps of 64 instead of 3C/64 in the first layer of every WN -- ONE K-step in the
-  128-column tile of the 256-channel kernel, `wide_tiles`, plus a 16-deep step that rebuilds the residual input)."""
+  16 rows; in_layers[0] o start: ONE gathered K-step of 64 instead of 3C/64 in the first layer of every WN, plus -- up to
+  256 channels -- a 16-deep step that rebuilds the residual input x_0 from the a0 plane)."""
   C_, M = hp.n_channels, hp.n_mel_channels
   per_flow = 0.0
-  one_step = wide_tiles and C_ == 256
   for i in range(hp.n_layers):
-    k1 = ((64 if one_step else 3 * 64) if i == 0 else 3 * C_) + 4 * M
-    if i == 0 and C_ in (128, 256):
+    k1 = (64 if i == 0 else 3 * C_) + 4 * M
+    if i == 0 and C_ <= 256:
       per_flow += 16 * C_                       # x_0 = W_start a0 + b_start on the matrix pipe (wn_res_a0)
     per_flow += 2 * C_ * k1 + (C_ * C_ if i < hp.n_layers - 1 else 0) + 16 * C_
   return per_flow * hp.n_flows
@@ -368,7 +367,7 @@ def infer_roofline(hp, B, T, steps, ms, cnt, traffic=None):
   launches_per_step = hp.n_flows * hp.n_layers
   flops_per_launch = 2.0 * wn_layer_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
   achieved = flops_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
-  executed_per_launch = 2.0 * wn_layer_executed_macs_per_group_step(hp, wide_tiles=B * T >= 1024) * (B * T * 32) / launches_per_step
+  executed_per_launch = 2.0 * wn_layer_executed_macs_per_group_step(hp) * (B * T * 32) / launches_per_step
   executed = executed_per_launch / (avg_wn_ms * 1e-3) / 1e12 if n_wn else 0.0
   return {"bound": "mfma", "kernel": "wn_layer_kernel", "achieved": round(achieved, 2),
           "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_DENSE_TFLOPS, 4),

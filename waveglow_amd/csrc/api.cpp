@@ -577,27 +577,27 @@ int wg_finalize(wg_handle* h) {
               fr[4] += wv * bst->data[ch];
             }
           }
-        lo.wA1f = reserve((size_t)3 * 2 * NW * MT * 2 * 64 * 8 * 2);
+        // ONE K-step for the three taps (wn_layer_kernel A0G): K index kk = 8 tap + j against a B tile whose 16-byte chunk
+        // `tap` is the first chunk (a0 | 1 | 0 0 0) of that tap's a0-plane row
+        lo.wA1f = reserve((size_t)2 * NW * MT * 2 * 64 * 8 * 2);
         _Float16* dst = (_Float16*)(blob.data() + lo.wA1f);
-        for (int u = 0; u < 2 * 3; ++u)
+        for (int u = 0; u < 2; ++u)
           for (int w = 0; w < NW; ++w)
             for (int mt = 0; mt < MT; ++mt)
               for (int k2 = 0; k2 < 2; ++k2)
                 for (int lane = 0; lane < 64; ++lane) {
-                  const int tap = u >> 1, k16 = (u & 1) * 2 + k2;
+                  const int k16 = u * 2 + k2;
                   const int r = lane & 31, hh = lane >> 5;
                   const bool tanh_row = mt < MB;
                   const int m = (tanh_row ? 0 : C) + 32 * (w * MB + (tanh_row ? mt : mt - MB)) + r;
                   const float rs = tanh_row ? kTanhScale : kSigmScale;
                   _Float16* d = dst + (((((size_t)u * NW + w) * MT + mt) * 2 + k2) * 64 + lane) * 8;
                   for (int j = 0; j < 8; ++j) {
-                    const int kk = k16 * 16 + 8 * hh + j;          // channel of the a0 plane (natural order)
-                    d[j] = (_Float16)(kk < 8 ? (float)(fold[((size_t)m * 3 + tap) * 8 + kk] * rs) : 0.0f);
+                    const int kk = k16 * 16 + 8 * hh + j;          // 8 tap + value index of the gathered tile row
+                    d[j] = (_Float16)(kk < 24 ? (float)(fold[((size_t)m * 3 + (kk >> 3)) * 8 + (kk & 7)] * rs) : 0.0f);
                   }
                 }
         if (f16) {
-          // ONE K-step for the three taps (wn_layer_kernel A0G): K index kk = 8 tap + j against a B tile whose 16-byte
-          // chunk `tap` is the first chunk (a0 | 1 | 0 0 0) of that tap's a0-plane row
           lo.wA1fx = reserve((size_t)2 * NW * 4 * 64 * 8 * 2);
           pack16(lo.wA1fx, 2, [&](int m, int, int kk) { return kk < 24 ? (float)fold[((size_t)m * 3 + (kk >> 3)) * 8 + (kk & 7)] : 0.0f; });
         }
@@ -757,6 +757,7 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     a.melT = w.melT;
     a.frag16 = wn_frag16(C, BN) ? 1 : 0;
     a.wStA = fold0 && wn_res_a0(C) ? (const _Float16*)(h->d_blob + fo.wStA) : nullptr;
+    a.a0_fold = fold0 ? 1 : 0;
     a.wA1c = (const _Float16*)((a.frag16 ? h->d_cond16 : h->d_cond) + h->cond_flow_bytes * k + h->cond_layer_bytes * i);
     a.wA1 = (const _Float16*)(h->d_blob + (a.frag16 ? (fold0 ? lo.wA1fx : lo.wA1x) : (fold0 ? lo.wA1f : lo.wA1)));
     a.bias1 = (const float*)(h->d_blob + lo.bias1);

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   // the plane row of tap t (the LDS-DMA takes a per-lane source: stage_B_piece), chunks 3-7 from the rows' own zero tails --
   // against in_layers[0] o start packed as [tap][8] along K (api.cpp wA1fx).  8 -> 6 K-steps for that launch.
   constexpr bool A0G = MODE == 0 && CX == 1 && NTAPS == 1;
-  static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && ((NKX >= 4 && NKX % 2 == 0) || NKX == 3)), "deep prefetch variant");
+  static_assert(!DEEP || (MODE == 0 && DEFER && HAS_COND && MT <= NT && NG <= NT && ((NKX >= 4 && NKX % 2 == 0) || NKX == 1)), "deep prefetch variant");
   static_assert(MODE == 0 || (TPW == 1 && CX == ((MODE == 2 || MODE == 4) ? 2 : 1) * (C / 64)) || (MODE == 3 && CX == 1), "training variants");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     }
 
     constexpr bool PIPE = !PLAIN && kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
-    constexpr bool RES_A0 = MODE == 0 && CX == 1 && wn_res_a0(C);       // first layer of a WN: x_0 rebuilt from the a0 plane
+    constexpr bool RES_A0 = A0G && wn_res_a0(C);                        // first layer of a WN: x_0 rebuilt from the a0 plane
     static_assert(!RES_A0 || (PIPE || !HAS_RES), "the a0 residual step lives in the pipelined epilogue");
     half8 a2r[PIPE ? K2 : 1];                                 // GEMM-2 weight fragments of this wave (pipelined epilogue)
     // ---- K loop (GEMM 1).  One K-step = 4 k16 sub-steps g = 0..3, each MT*NT MFMAs on fragments q[g][.]
@@ -740,16 +740,15 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       using P0 = std::integral_constant<int, 0>;
       using P1 = std::integral_constant<int, 1>;
       //        parity more  more2 ncond first
-      kstep_d(P0{}, T_{}, T_{}, F_{}, T_{}, 0);
-      if constexpr (NKX == 3) {                                         // first layer of a WN: three a0-plane steps
-        kstep_d(P1{}, T_{}, T_{}, F_{}, F_{}, 1);
-        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, 2);                       // last tap step: the next B tile is a conditioning tile
-        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, 3);                       // five conditioning steps (the host checks n_cond_steps)
-        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, 4);
-        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, 5);
-        kstep_d(P0{}, T_{}, F_{}, T_{}, F_{}, 6);
-        kstep_d(P1{}, F_{}, F_{}, F_{}, F_{}, 7);
+      if constexpr (NKX == 1) {                                         // first layer of a WN: one gathered a0-plane step (A0G)
+        kstep_d(P0{}, T_{}, T_{}, T_{}, T_{}, 0);                       // the next B tile is a conditioning tile
+        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, 1);                       // five conditioning steps (the host checks n_cond_steps)
+        kstep_d(P0{}, T_{}, T_{}, T_{}, F_{}, 2);
+        kstep_d(P1{}, T_{}, T_{}, T_{}, F_{}, 3);
+        kstep_d(P0{}, T_{}, F_{}, T_{}, F_{}, 4);
+        kstep_d(P1{}, F_{}, F_{}, F_{}, F_{}, 5);
       } else {
+        kstep_d(P0{}, T_{}, T_{}, F_{}, T_{}, 0);
 #pragma clang loop unroll(disable)
         for (int ks = 1; ks < NKX - 1; ks += 2) {                       // NKX even: pairs (odd, even)
           kstep_d(P1{}, T_{}, T_{}, F_{}, F_{}, ks);
@@ -1371,7 +1370,7 @@ static hipError_t launch_wn_tttt(const WnLayerArgs& a, hipStream_t s) {
   constexpr int NW = WnCfg<C>::NW;
   constexpr bool M16 = wn_frag16(C, BN) && MODE == 0 && !DEEP;   // the host packs GEMM-1 weights for it (api.cpp)
   if (M16 != (a.frag16 != 0)) return hipErrorInvalidValue;
-  if (MODE == 0 && CX == 1 && wn_res_a0(C) && HAS_RES && !a.wStA) return hipErrorInvalidValue;
+  if (MODE == 0 && CX == 1 && NTAPS == 1 && wn_res_a0(C) && HAS_RES && !a.wStA) return hipErrorInvalidValue;
   constexpr int smem = MODE == 4 ? (BN * (2 * C + 16) > 2 * BN * 128 ? BN * (2 * C + 16) : 2 * BN * 128)
                                  : 2 * BN * 128 + (MODE >= 2 ? 0 : BN * (2 * C + 16) + 3 * C * 4 + (kWesLds ? (C / 32) * 1024 : 0));
   static bool attr_done_dev[64] = {};      // the attribute is per device: keyed by the launch's (current) device
@@ -1397,15 +1396,12 @@ static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
   if constexpr (kDeep && C == 256 && BN == 64 && TPW == 1) {
     const char* e = getenv("WG_DISABLE_DEEP");
     if (a.n_cond_steps == 5 && !(e && *e == '1')) {
-      if (a.x_chunks_per_tap == 1) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1, 0, 3, true, true>(a, s);
+      if (a.a0_fold) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1, 0, 1, true, true>(a, s);
       return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64, 0, 3, true, true>(a, s);
     }
   }
-  if (a.x_chunks_per_tap == 1) {
-    // first layer with the start fold: the 16x16x32 tile shapes take the three taps in one K-step (A0G; wA1fx is packed for it)
-    if constexpr (wn_frag16(C, BN)) return launch_wn_tttt<C, BN, HAS_RES, TPW, 1, 0, 1>(a, s);
-    return launch_wn_tttt<C, BN, HAS_RES, TPW, 1>(a, s);
-  }
+  // first layer with the start fold: the three taps of the a0 plane in one gathered K-step (A0G; wA1 is packed for it)
+  if (a.a0_fold) return a.x_chunks_per_tap == 1 ? launch_wn_tttt<C, BN, HAS_RES, TPW, 1, 0, 1>(a, s) : hipErrorInvalidValue;
   return launch_wn_tttt<C, BN, HAS_RES, TPW, C / 64>(a, s);
 }
 template <int C, int BN, bool HAS_RES>
