@@ -45,13 +45,12 @@ def wn_layer_macs_per_group_step(hp) -> float:
 def wn_layer_executed_macs_per_group_step(hp) -> float:
   """MACs the wn_layer launches actually EXECUTE per group-timestep, after the algebraic folds of DESIGN.md section 2
   (cond_layer o upsample: K 640 -> 320; WN.end folded into the skip rows: the skip half of res_skip and `end` become
-  16 rows; in_layers[0] o start: ONE gathered K-step of 64 instead of 3C/64 in the first layer of every WN, plus -- up to
-  256 channels -- a 16-deep step that rebuilds the residual input x_0 from the a0 plane)."""
+  16 rows; in_layers[0] o start: ONE gathered K-step of 64 instead of 3C/64 in the first layer of every WN, plus a 16-deep step that rebuilds the residual input x_0 from the a0 plane)."""
   C_, M = hp.n_channels, hp.n_mel_channels
   per_flow = 0.0
   for i in range(hp.n_layers):
     k1 = (64 if i == 0 else 3 * C_) + 4 * M
-    if i == 0 and C_ <= 256:
+    if i == 0:
       per_flow += 16 * C_                       # x_0 = W_start a0 + b_start on the matrix pipe (wn_res_a0)
     per_flow += 2 * C_ * k1 + (C_ * C_ if i < hp.n_layers - 1 else 0) + 16 * C_
   return per_flow * hp.n_flows

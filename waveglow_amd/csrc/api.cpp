@@ -493,9 +493,9 @@ int wg_finalize(wg_handle* h) {
       // A fragment of the 32x32x16 MFMA, [wave][lane = (row r, half)][8]: row r = channel 32 w + r; lanes 0-31 hold the fp16
       // hi parts of (W_start[ch][0..h-1], b_start[ch] at k = 4), lanes 32-63 the lo parts -- against the a0 plane row, which
       // carries (a0 | 1 | 0 0 0) at positions 0-7 and again at 8-15 (flow_kernel)
-      fo.wStA = reserve((size_t)NW * 64 * 8 * 2);
+      fo.wStA = reserve((size_t)(C / 32) * 64 * 8 * 2);
       _Float16* d = (_Float16*)(blob.data() + fo.wStA);
-      for (int w = 0; w < NW; ++w)
+      for (int w = 0; w < C / 32; ++w)
         for (int lane = 0; lane < 64; ++lane) {
           const int ch = 32 * w + (lane & 31);
           for (int j = 0; j < 8; ++j) {

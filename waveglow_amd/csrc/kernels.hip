@@ -521,7 +521,6 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 
     constexpr bool PIPE = !PLAIN && kPipeEpi && HAS_RES && MB == 1;     // pipelined epilogue (below); else the sequential one
     constexpr bool RES_A0 = A0G && wn_res_a0(C);                        // first layer of a WN: x_0 rebuilt from the a0 plane
-    static_assert(!RES_A0 || (PIPE || !HAS_RES), "the a0 residual step lives in the pipelined epilogue");
     half8 a2r[PIPE ? K2 : 1];                                 // GEMM-2 weight fragments of this wave (pipelined epilogue)
     // ---- K loop (GEMM 1).  One K-step = 4 k16 sub-steps g = 0..3, each MT*NT MFMAs on fragments q[g][.]
     // (weights) x bf[g&1][.] (activations, read from LDS one sub-step ahead).  Every VMEM / LDS instruction is
@@ -1027,7 +1026,8 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       return *(const half8*)(acts_rd + nt * 32 * ACT_ROW + k16 * 32);
     };
     constexpr int PF = 8 / MB;                // GEMM2 A-fragment prefetch depth (per 32-channel block)
-    half8 xres[MB][NT][2];
+    half8 xres[RES_A0 ? 1 : MB][RES_A0 ? 1 : NT][2];
+    half8 a0f[RES_A0 ? NT : 1], wst[RES_A0 ? MB : 1];     // sequential epilogue, RES_A0: a0-plane row fragments, start weights
     half8 a2[MB][PF];
     const half8* const p2 = (const half8*)a.wA2 + (size_t)wave * MB * K2 * 64 + laneo;
     f32x16 acc2[MB][NT];
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
       // lo parts (k = 8..12), so the sum carries ~fp32 weights and is never rounded to fp16 on its own.
       half8 idA[RES_A0 ? 1 : 2];
       if constexpr (RES_A0) {
-        idA[0] = ((const half8*)a.wStA)[wave * 64 + laneo];
+        idA[0] = ((const half8*)a.wStA)[blk * 64 + laneo];
       } else {
         const int pr = 16 * ((lno >> 2) & 1) + 4 * (lno >> 3) + (lno & 3);     // chan_to_pos of row r = lno inside a 32-block
 #pragma unroll
@@ -1223,15 +1223,23 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
     // residual input x (this tile, this wave's channels: lane (n, h) owns positions [32*blk + 16h, +16) of
     // column n = 32 contiguous bytes) and the first GEMM2 weight fragments.
     if constexpr (HAS_RES) {
+      if constexpr (RES_A0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a0f[nt] = *(const half8*)(a.x_tap + ((size_t)r0 + nt * 32 + lno) * 64 + lho * 8);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) wst[mb] = ((const half8*)a.wStA)[(wave * MB + mb) * 64 + laneo];
+      }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int blk = wave * MB + mb;
+        if constexpr (!RES_A0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
-          const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lho * 16);
-          xres[mb][nt][0] = xp[0];
-          xres[mb][nt][1] = xp[1];
+          for (int nt = 0; nt < NT; ++nt) {
+            const size_t row = (size_t)(blk >> 1) * R + r0 + nt * 32 + lno;
+            const half8* xp = (const half8*)(a.x_in + row * 64 + (blk & 1) * 32 + lho * 16);
+            xres[mb][nt][0] = xp[0];
+            xres[mb][nt][1] = xp[1];
+          }
         }
 #pragma unroll
         for (int i = 0; i < PF; ++i) a2[mb][i] = p2[((size_t)mb * K2 + i) * 64];
@@ -1293,12 +1301,19 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2)];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (RES_A0) {                    // x_0 = W_start a0 + b_start, one MFMA step (see the pipelined epilogue)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            acc2[mb][nt][r] = (float)xres[mb][nt][0][r] + bv[r];
-            acc2[mb][nt][8 + r] = (float)xres[mb][nt][1][r] + bv[8 + r];
+            for (int r = 0; r < 16; ++r) acc2[mb][nt][r] = bv[r];
+            acc2[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wst[mb], a0f[nt], acc2[mb][nt], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              acc2[mb][nt][r] = (float)xres[mb][nt][0][r] + bv[r];
+              acc2[mb][nt][8 + r] = (float)xres[mb][nt][1][r] + bv[8 + r];
+            }
           }
+        }
       }
     }
 

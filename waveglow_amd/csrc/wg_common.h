@@ -70,8 +70,8 @@ constexpr bool wn_frag16(int C, int BN) { return C == 256 && BN == 128; }
 
 // First layer of a WN in the inference kernels: the residual input x_0 = W_start a0 + b_start (model.py:117) is rebuilt from
 // the a0 plane by one MFMA step of the epilogue (weights hi + lo fp16, WnLayerArgs::wStA), so flow_kernel does not write
-// the x_0 planes at all (2C bytes per group-timestep and flow).  Channel counts whose kernels have the pipelined epilogue.
-constexpr bool wn_res_a0(int C) { return C <= 256; }
+// the x_0 planes at all (2C bytes per group-timestep and flow).
+constexpr bool wn_res_a0(int) { return true; }
 
 struct WnLayerArgs {
   const _Float16* x_in;     // [C/64][R][64] position-major
@@ -101,8 +101,8 @@ struct WnLayerArgs {
   int frag16 = 0;           // wA1 / wA1c are 16x16x32 fragments (must equal wn_frag16(C, BN) of the inference launch)
   int a0_fold = 0;          // first layer of a WN with the start fold: x_tap is the a0 plane, wA1 is in_layers[0] o start packed
                             // [tap][8] along ONE K-step (wn_layer_kernel A0G); x_chunks_per_tap == 1
-  const _Float16* wStA = nullptr;   // first layer with the start fold (x_chunks_per_tap == 1), wn_res_a0(C): [NW][64][8] A fragments
-                            // (row r = channel 32 w + r; k = 0..3 W_start, k = 4 b_start; lanes 0-31 hi, 32-63 lo parts)
+  const _Float16* wStA = nullptr;   // first layer with the start fold (x_chunks_per_tap == 1), wn_res_a0(C): [C/32][64][8] A fragments
+                            // (row r = channel 32 blk + r; k = 0..3 W_start, k = 4 b_start; lanes 0-31 hi, 32-63 lo parts)
   unsigned long long* stamps;   // diagnostic build only (-DWG_STAMPS): [n_tiles][8] s_memtime per phase
   // ---- training forward only (wn_layer_kernel<..., TR = true>, train_api.cpp); null / unused for inference
   const _Float16* sp;       // upsampled, squeezed spectrogram planes [M8/64 chunks][R][64] (position-major): the B operand
