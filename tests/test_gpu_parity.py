@@ -97,6 +97,23 @@ def test_infer_ragged_lengths_vs_oracle(B, T, force_bn, monkeypatch):
 
 
 @pytest.mark.parametrize("force_bn", ["128", "64"])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (2, 33)])
+def test_infer_c256_edge_tiles_vs_oracle(B, T, force_bn, monkeypatch):
+  """256 channels at lengths far below a tile: the 16x16x32 loop (128 columns) and the deep-prefetch 32x32x16 loop (64
+  columns) on tiles that are mostly guard rows and padding, the first layer's gathered tap tile at the plane's edges."""
+  from oracle import torch_oracle as O
+  monkeypatch.setenv("WG_FORCE_BN", force_bn)
+  hp = HParams(n_layers=5, n_flows=4, n_early_every=2)
+  sd = synthetic.make_state_dict(hp, seed=21)
+  mel = synthetic.make_mel(B, T, seed=T)
+  z_init, z_early = synthetic.make_noise(hp, B, 32 * T, seed=200 + T)
+  with torch.no_grad():
+    ref = O.infer_ref(sd, mel, z_init, z_early, 0.7, oracle_cfg_from_hp(hp))
+  out = gpu_infer(build_model(hp, sd), mel, z_init, z_early, 0.7)
+  assert rms(out - ref) <= RMS_TOL, rms(out - ref)
+
+
+@pytest.mark.parametrize("force_bn", ["128", "64"])
 def test_infer_c256_vs_oracle_medium(force_bn, monkeypatch):
   """Both WN tile widths (128 columns = default, 64 = small-workload variant) against the oracle."""
   from oracle import torch_oracle as O

@@ -357,7 +357,11 @@ __global__ void __launch_bounds__(NW * 64) wn_layer_kernel(const WnLayerArgs a) 
   auto load_A16 = [&](int ks, int s_, int m, half8& dst) {
     const char* base = ks < NKX ? (const char*)a.wA1 : wA1c_p;
     const int kl = ks < NKX ? ks : ks - NKX;
+#ifndef WG_DBG_NO_ALOAD
     gload16<0>(dst, base + ((size_t)(2 * kl + s_) * NW + wave) * (NAH * 1024) + m * 1024, a_voff);
+#else
+    asm volatile("" : "=v"(dst));
+#endif
   };
   // column -> (utterance, frame): rr = row inside the phase block, one of the BN consecutive rows of the current tile.
   // The utterance of the tile's first row (tile_b0, wave-uniform: one scalar division per tile) is at most one
