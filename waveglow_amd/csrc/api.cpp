@@ -741,8 +741,15 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
   const wg_config& c = h->cfg;
   const int C = c.n_channels;
   int BN = wn_block_n(C);
-  // small workloads: 64-column tiles double the workgroup count when 128-column tiles would leave CUs idle
-  if (BN == 128 && (int64_t)kPhases * (g.Rp / 128) < (int64_t)h->n_cu) BN = 64;
+  // Small workloads: 64-column tiles double the workgroup count when 128-column tiles would leave CUs idle -- when that
+  // buys whole rounds.  A 64-column tile takes ~0.6 of a 128-column tile's time (measured at 256 channels: 22.7 vs 38.5 us
+  // for a one-round launch), so compare rounds x tile time: 128 tiles on 256 CUs -> 64-column tiles fill the chip in one
+  // round (configs[0]); 224 tiles -> two rounds of 64-column tiles lose to one round of 128-column ones (+18 % at 1 x 80x864).
+  if (BN == 128) {
+    const int64_t t128 = (int64_t)kPhases * (g.Rp / 128), ncu = h->n_cu > 0 ? h->n_cu : 1;
+    const int64_t r128 = (t128 + ncu - 1) / ncu, r64 = (2 * t128 + ncu - 1) / ncu;
+    if (t128 < 4 * ncu && 6 * r64 < 10 * r128) BN = 64;
+  }
   if (BN == 128 && h->force_bn == 64) BN = 64;
   if (h->force_bn == 128 && wn_block_n(C) == 128) BN = 128;
   const FlowOffsets& fo = h->flows[k];

@@ -1425,8 +1425,12 @@ static hipError_t launch_wn_ttt(const WnLayerArgs& a, hipStream_t s) {
 }
 template <int C, int BN, bool HAS_RES>
 static hipError_t launch_wn_tt(const WnLayerArgs& a, hipStream_t s) {
-  // two tiles per workgroup amortise the launch and prefetch across the tile seam, but need >= 2 tiles per CU
-  if (a.n_tiles >= 2 * kTilesPerWG * a.n_cu) return launch_wn_ttt<C, BN, HAS_RES, kTilesPerWG>(a, s);
+  // two tiles per workgroup amortise the launch and prefetch across the tile seam, but need >= 2 tiles per CU -- and must not
+  // cost a round: 1120 tiles on 256 CUs are 5 rounds of single tiles but 3 rounds of pairs = 6 tile times (batch 5 x 80x864)
+  const int ncu = a.n_cu > 0 ? a.n_cu : 1;
+  const int rounds1 = (a.n_tiles + ncu - 1) / ncu;
+  const int rounds2 = ((a.n_tiles + kTilesPerWG - 1) / kTilesPerWG + ncu - 1) / ncu * kTilesPerWG;
+  if (a.n_tiles >= 2 * kTilesPerWG * ncu && rounds2 <= rounds1) return launch_wn_ttt<C, BN, HAS_RES, kTilesPerWG>(a, s);
   return launch_wn_ttt<C, BN, HAS_RES, 1>(a, s);
 }
 template <int C>
