@@ -87,7 +87,7 @@ constexpr float kSigmScale = -1.4426950408889634f;   // -log2(e)
 
 struct LayerOffsets {
   size_t wA1, bias1, wA2, bias2, wEs;
-  size_t wA1f = 0;   // layer 0 only: in_layers[0] o start folded onto the a0 plane, 3 K-steps
+  size_t wA1f = 0;   // layer 0 only: in_layers[0] o start folded onto the a0 plane, one gathered K-step ([tap][8] along K)
   size_t wA1x = 0, wA1fx = 0;   // the same two as 16x16x32 fragments (wn_frag16: the 128-column tile's K loop)
 };
 struct FlowOffsets {
@@ -758,7 +758,7 @@ static int run_wn(wg_handle* h, int k, const RowGeom& g, Workspace& w, _Float16*
     WnLayerArgs a;
     a.x_in = cur;
     a.x_out = oth;
-    const bool fold0 = (i == 0) && h->fold_start;       // in_layers[0] o start on the a0 plane (3 K-steps)
+    const bool fold0 = (i == 0) && h->fold_start;       // in_layers[0] o start on the a0 plane (one gathered K-step)
     a.x_tap = fold0 ? w.A0 : cur;
     a.x_chunks_per_tap = fold0 ? 1 : C / 64;
     a.melT = w.melT;

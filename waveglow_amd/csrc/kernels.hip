@@ -193,9 +193,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // and goes HBM/L2 -> LDS by LDS-DMA.  All VMEM of the K loop is hand-counted (see glds16).
 // CX = 64-channel chunks per dilated tap of GEMM 1: C/64 normally; 1 for the FIRST layer of a WN, whose input
 // x_0 = start(a0) (model.py:117) is itself linear in the <= 4 coupling channels a0, so in_layers[0] o start collapses
-// to a [2C x (3 taps x 5)] matrix on the rows of the a0 plane (a0 | 1) that flow_kernel writes next to x_0:
-// 3 K-steps instead of 3C/64 (the bias of start rides on the constant-1 channel, which is 0 in the guard rows, so
-// the convolution's zero padding of x_0 stays exact).
+// to a [2C x (3 taps x 5)] matrix on the rows of the a0 plane (a0 | 1) that flow_kernel writes INSTEAD of x_0:
+// ONE gathered K-step (NTAPS = 1, see A0G) instead of 3C/64 (the bias of start rides on the constant-1 channel, which is 0
+// in the guard rows, so the convolution's zero padding of x_0 stays exact); the residual input x_0 itself is rebuilt from
+// the same plane by one MFMA step of the epilogue (RES_A0).
 // TR = training forward (model.py:178-221 under autograd): the conditioning K-steps read the upsampled spectrogram
 // planes a.sp (weights change every optimiser step, so the per-phase cond_layer o upsample fold would have to be rebuilt
 // every step), and the gate also writes tanh, sigmoid and acts as fp16 planes for the backward pass (train.hip).
